@@ -1,0 +1,192 @@
+/*
+ * rlhip.h -- C ABI of librlhip.so: an MI355X (gfx950) native LambdaMART trainer that is a
+ * drop-in for the training / scoring path behind RankLib's `-ranker 6`.
+ *
+ * This is the drop-in boundary.  Everything a JNI shim, the ctypes host
+ * mirror (ranklib_amd/) or a native CLI needs goes through these entry points: plain
+ * pointers and sizes, no C++/torch types, int status codes, no exceptions across the ABI.
+ * INTEGRATION.md shows the JNI binding and the Java host class a RankLib maintainer would add.
+ *
+ * Reference interfaces replaced (paths relative to
+ * /root/reference/src/main/java/ciir/umass/edu/):
+ *
+ *   rl_create / rl_set_*        <- RankerFactory.createRanker + Ranker ctor/setters
+ *                                  learning/RankerFactory.java:60-70, learning/Ranker.java:52-74,
+ *                                  static parameters learning/tree/LambdaMART.java:37-42
+ *   rl_init                     <- LambdaMART.init()            learning/tree/LambdaMART.java:68-166
+ *   rl_boost_round(s)           <- one iteration of learn()     learning/tree/LambdaMART.java:180-251
+ *   rl_finish                   <- tail of learn()              learning/tree/LambdaMART.java:253-265
+ *   rl_get_tree / rl_num_trees  <- getEnsemble()                learning/tree/LambdaMART.java:327-329,
+ *                                  Ensemble/RegressionTree/Split learning/tree/Ensemble.java:72-100
+ *   rl_predict                  <- LambdaMART.eval -> Ensemble.eval  learning/tree/LambdaMART.java:275-277,
+ *                                  learning/tree/Ensemble.java:110-116, learning/tree/Split.java:115-125
+ *   rl_model_to_text/from_text  <- model() / loadFromString()   learning/tree/LambdaMART.java:290-310,
+ *                                  learning/tree/Ensemble.java:45-70,119-130, learning/tree/Split.java:132-155
+ *
+ * Error convention: the reference throws unchecked RankLibError (utilities/RankLibError.java:25-42).
+ * Here every call returns RL_OK (0) or a negative code and leaves a message retrievable with
+ * rl_last_error() (thread-local); a JNI shim rethrows it as RankLibError.create(msg).
+ *
+ * Threading: like the reference (single caller, global statics) a handle must be used by one
+ * thread at a time; distinct handles are independent.
+ *
+ * Ownership: the caller owns every buffer it passes; rl_set_* copy to HBM and never retain the
+ * pointers.  Output buffers are caller-allocated.
+ */
+#ifndef RLHIP_H
+#define RLHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RLHIP_ABI_VERSION 1
+
+enum {
+    RL_OK = 0,
+    RL_ERR_INVALID = -1,     /* bad argument / bad input data (e.g. negative label: learning/DataPoint.java:70-73) */
+    RL_ERR_HIP = -2,         /* HIP runtime or kernel failure, message holds file:line */
+    RL_ERR_STATE = -3,       /* call out of order (e.g. rl_boost_round before rl_init) */
+    RL_ERR_UNSUPPORTED = -4, /* valid for RankLib but not built yet (documented in DESIGN.md) */
+    RL_ERR_NO_DEVICE = -5,   /* no gfx950 device visible: there is NO CPU fallback */
+    RL_ERR_COMM = -6         /* RCCL failure */
+};
+
+enum { RL_METRIC_NDCG = 0 };            /* metric/NDCGScorer.java (others: SURVEY.md 8f "next") */
+
+enum {                                  /* rl_params.flags */
+    RL_FLAG_FAST_LEAF = 1,              /* leaf sums as exact-f64 tree sums instead of emulating the Java float
+                                           running sums (learning/tree/LambdaMART.java:401-408).  NOT parity. */
+    RL_FLAG_TIMING = 2                  /* record HIP events around the dominant kernels (rl_get_timing) */
+};
+
+typedef struct rl_trainer rl_trainer;   /* opaque */
+typedef struct rl_model rl_model;       /* opaque: a loaded ensemble for scoring only */
+
+typedef struct {
+    int32_t n_trees;            /* LambdaMART.nTrees            default 1000 */
+    int32_t n_leaves;           /* LambdaMART.nTreeLeaves       default 10   */
+    int32_t n_threshold;        /* LambdaMART.nThreshold        default 256 (-1: every distinct value) */
+    int32_t min_leaf_support;   /* LambdaMART.minLeafSupport    default 1    */
+    int32_t early_stop_rounds;  /* LambdaMART.nRoundToStopEarly default 100  */
+    float   learning_rate;      /* LambdaMART.learningRate      default 0.1F (a Java float) */
+    int32_t metric;             /* RL_METRIC_NDCG */
+    int32_t metric_k;           /* NDCG@k, default 10 (metric/DCGScorer.java:21) */
+    int32_t device;             /* HIP device ordinal */
+    int32_t flags;              /* RL_FLAG_* */
+} rl_params;
+
+/* One regression tree: nodes in pre-order (root 0, left subtree first) == Split.leaves() order
+ * (learning/tree/Split.java:100-113).  Arrays are caller-allocated with `cap` entries
+ * (2*n_leaves-1 always suffices). */
+typedef struct {
+    int32_t  n_nodes;     /* out */
+    int32_t  cap;         /* in  */
+    int32_t *feature;     /* feature ID as written to the model file; -1 = leaf   (Split.featureID) */
+    float   *threshold;   /* Split.threshold: go left iff value <= threshold      (Split.java:118)  */
+    int32_t *left;        /* child node index, -1 for leaves */
+    int32_t *right;
+    float   *output;      /* leaf output (Split.avgLabel set by updateTreeOutput), 0 for internal nodes */
+    double  *deviance;    /* optional (may be NULL): Split.deviance */
+    int32_t *count;       /* optional (may be NULL): training samples that reached the node */
+} rl_tree;
+
+/* ---- library ----------------------------------------------------------------------------- */
+int         rl_abi_version(void);
+const char *rl_last_error(void);
+int         rl_device_count(int32_t *n);
+void        rl_params_default(rl_params *p);              /* the defaults of LambdaMART.java:37-42 */
+
+/* ---- trainer ----------------------------------------------------------------------------- */
+int  rl_create(const rl_params *p, rl_trainer **out);
+void rl_destroy(rl_trainer *t);
+
+/* Training set.  X is row-major [n_docs][n_features], already resolved through
+ * DataPoint.getFeatureValue(feature_ids[f]) (missing / NaN -> 0: learning/DenseDataPoint.java:21-32).
+ * qoff[n_queries+1]: docs of query q are qoff[q]..qoff[q+1]-1 (file order, learning/RankList.java).
+ * feature_ids[n_features]: the IDs written into the model (Ranker.features); NULL => 1..n_features.
+ * qkey[n_queries]: optional; equal keys == equal qid strings (idealGains cache quirk,
+ * metric/NDCGScorer.java:114-122,134-143); NULL => all distinct. */
+int rl_set_train(rl_trainer *t, const float *X, int64_t n_docs, int32_t n_features, const float *labels,
+                 const int32_t *qoff, int32_t n_queries, const int32_t *feature_ids, const int32_t *qkey);
+/* Ranker.setValidationSet (learning/Ranker.java:68-70); same layout, same feature columns. */
+int rl_set_validation(rl_trainer *t, const float *X, int64_t n_docs, const float *labels, const int32_t *qoff,
+                      int32_t n_queries, const int32_t *qkey);
+
+int rl_init(rl_trainer *t);
+
+/* One boosting round, synchronous.  out may be NULL.  *stop is set to 1 when the early-stop test
+ * (learning/tree/LambdaMART.java:248) fires after this round.  train_metric / valid_metric are the
+ * float-accumulated per-round values of :216 / :237 (valid_metric untouched without validation data). */
+int rl_boost_round(rl_trainer *t, rl_tree *out, float *train_metric, float *valid_metric, int32_t *stop);
+
+/* Enqueue n rounds without any host synchronisation (no validation set allowed: early stopping needs
+ * the host).  rl_sync waits for them; trees and per-round metrics are then available through
+ * rl_get_tree / rl_get_round_metrics. */
+int rl_boost_rounds_async(rl_trainer *t, int32_t n);
+int rl_sync(rl_trainer *t);
+
+/* End of learn(): rollback to the best validation model, final scorer.score(rank(samples)) with
+ * Ensemble.eval's float accumulation.  valid_score may be NULL. */
+int rl_finish(rl_trainer *t, double *train_score, double *valid_score);
+
+int rl_num_trees(const rl_trainer *t, int32_t *n);
+int rl_get_tree(const rl_trainer *t, int32_t i, rl_tree *out);
+int rl_get_round_metrics(const rl_trainer *t, int32_t round, float *train_metric, float *valid_metric);
+int rl_best_validation(const rl_trainer *t, int32_t *best_round, double *best_score);
+
+/* Ensemble.eval over rows (float accumulation in tree order).  X row-major [n][n_features] with the
+ * trainer's feature columns. */
+int rl_predict(rl_trainer *t, const float *X, int64_t n_docs, float *out);
+
+/* ---- model text (RankLib's <ensemble> format) -------------------------------------------- */
+/* Writes LambdaMART.model() into buf (NUL-terminated).  Returns RL_OK and *needed = bytes required
+ * incl. NUL; if cap < *needed nothing is written. */
+int  rl_model_to_text(const rl_trainer *t, char *buf, int64_t cap, int64_t *needed);
+int  rl_model_from_text(const char *text, int32_t device, rl_model **out);
+void rl_model_destroy(rl_model *m);
+int  rl_model_num_trees(const rl_model *m, int32_t *n);
+/* Features used by the model: Ensemble.getFeatures (learning/tree/Ensemble.java:132-134). */
+int  rl_model_features(const rl_model *m, int32_t *ids, int32_t cap, int32_t *n);
+/* X row-major [n][row_stride]; feature ID f is read from column f (column 0 unused, like DataPoint.fVals);
+ * IDs >= row_stride read as 0 (the -missingZero behaviour). */
+int  rl_model_predict(rl_model *m, const float *X, int64_t n_docs, int32_t row_stride, float *out);
+
+/* ---- multi-GPU (one process per GPU; queries sharded across ranks) ---------- */
+#define RL_UNIQUE_ID_BYTES 128
+int rl_dist_unique_id(void *id_out /* RL_UNIQUE_ID_BYTES */);       /* call on rank 0, broadcast out of band */
+/* Must be called before rl_init.  Each rank passes ITS shard of the queries to rl_set_train; the
+ * per-split histograms (and the few per-round scalars) are summed across ranks with RCCL. */
+int rl_dist_init(rl_trainer *t, const void *id, int32_t rank, int32_t n_ranks);
+
+/* ---- introspection for parity tests and the roofline report ------------------------------- */
+enum {
+    RL_ARR_LAMBDA = 1,       /* double[n_docs]  pseudoResponses of the last round */
+    RL_ARR_WEIGHT = 2,       /* double[n_docs] */
+    RL_ARR_SCORE = 3,        /* double[n_docs]  modelScores */
+    RL_ARR_VALID_SCORE = 4,  /* double[n_valid_docs] */
+    RL_ARR_NBINS = 5,        /* int32[n_features]           thresholds[f].length */
+    RL_ARR_THRESHOLDS = 6,   /* float[n_features*stride]    rows padded to `stride` = max nbins */
+    RL_ARR_BINS = 7,         /* uint16[n_features*n_docs]   sampleToThresholdMap, feature-major */
+    RL_ARR_ROOT_COUNT = 8,   /* int32[n_features*stride]    cumulative root counts */
+    RL_ARR_ROOT_SUM = 9,     /* double[n_features*stride]   cumulative root sums of the last round */
+    RL_ARR_QUANT = 10,       /* int64[n_docs]               fixed-point lambdas of the last round */
+    RL_ARR_ROOT_SUM_FIXED = 11, /* int64[2*n_features*stride] (hi,lo) 128-bit cumulative fixed-point sums */
+    RL_ARR_NDCG_PER_QUERY = 12  /* double[n_queries] of the last round */
+};
+int rl_bin_stride(const rl_trainer *t, int32_t *stride);
+int rl_quant_exponent(const rl_trainer *t, int32_t *e);   /* q = rint(lambda * 2^e) in the last round */
+int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes);
+
+enum { RL_KERNEL_HIST_ROOT = 0, RL_KERNEL_HIST_NODE = 1, RL_KERNEL_LAMBDA = 2, RL_KERNEL_COUNT_ = 3 };
+/* With RL_FLAG_TIMING: accumulated HIP-event time (ms), launch count and algorithmic bytes of a kernel
+ * since the last rl_reset_timing. */
+int rl_get_timing(rl_trainer *t, int32_t kernel, double *total_ms, int64_t *launches, double *alg_bytes);
+int rl_reset_timing(rl_trainer *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,322 @@
+"""ctypes binding of librlhip.so (include/rlhip.h).
+
+The library is built in-tree (ranklib_amd/lib/librlhip.so) by ranklib_amd/csrc/Makefile.
+There is no fallback: if the shared object is missing or no gfx950 device is visible the calls raise
+RankLibError, exactly like the reference's unchecked error convention (utilities/RankLibError.java).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librlhip.so")
+
+
+class RankLibError(RuntimeError):
+    """Mirrors ciir.umass.edu.utilities.RankLibError (utilities/RankLibError.java:9-43)."""
+
+
+class RlParams(C.Structure):
+    _fields_ = [("n_trees", C.c_int32), ("n_leaves", C.c_int32), ("n_threshold", C.c_int32),
+                ("min_leaf_support", C.c_int32), ("early_stop_rounds", C.c_int32), ("learning_rate", C.c_float),
+                ("metric", C.c_int32), ("metric_k", C.c_int32), ("device", C.c_int32), ("flags", C.c_int32)]
+
+
+class RlTree(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("cap", C.c_int32), ("feature", C.POINTER(C.c_int32)),
+                ("threshold", C.POINTER(C.c_float)), ("left", C.POINTER(C.c_int32)),
+                ("right", C.POINTER(C.c_int32)), ("output", C.POINTER(C.c_float)),
+                ("deviance", C.POINTER(C.c_double)), ("count", C.POINTER(C.c_int32))]
+
+
+RL_FLAG_FAST_LEAF, RL_FLAG_TIMING = 1, 2
+ARR = dict(LAMBDA=1, WEIGHT=2, SCORE=3, VALID_SCORE=4, NBINS=5, THRESHOLDS=6, BINS=7, ROOT_COUNT=8, ROOT_SUM=9,
+           QUANT=10, ROOT_SUM_FIXED=11, NDCG_PER_QUERY=12)
+KERNEL = dict(HIST_ROOT=0, HIST_NODE=1, LAMBDA=2)
+
+# every symbol include/rlhip.h declares (tests/test_abi.py checks the .so exports all of them)
+ABI_SYMBOLS = [
+    "rl_abi_version", "rl_last_error", "rl_device_count", "rl_params_default", "rl_create", "rl_destroy",
+    "rl_set_train", "rl_set_validation", "rl_init", "rl_boost_round", "rl_boost_rounds_async", "rl_sync",
+    "rl_finish", "rl_num_trees", "rl_get_tree", "rl_get_round_metrics", "rl_best_validation", "rl_predict",
+    "rl_model_to_text", "rl_model_from_text", "rl_model_destroy", "rl_model_num_trees", "rl_model_features",
+    "rl_model_predict", "rl_dist_unique_id", "rl_dist_init", "rl_bin_stride", "rl_quant_exponent", "rl_get_array",
+    "rl_get_timing", "rl_reset_timing",
+]
+
+_lib = None
+
+
+def lib():
+    """Load librlhip.so; fail loudly if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RankLibError("librlhip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C ranklib_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32p = C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_float)
+    L.rl_abi_version.restype = C.c_int
+    L.rl_last_error.restype = C.c_char_p
+    L.rl_device_count.argtypes = [C.POINTER(i32)]
+    L.rl_params_default.argtypes = [C.POINTER(RlParams)]
+    L.rl_params_default.restype = None
+    L.rl_create.argtypes = [C.POINTER(RlParams), C.POINTER(vp)]
+    L.rl_destroy.argtypes = [vp]
+    L.rl_destroy.restype = None
+    L.rl_set_train.argtypes = [vp, vp, i64, i32, vp, vp, i32, vp, vp]
+    L.rl_set_validation.argtypes = [vp, vp, i64, vp, vp, i32, vp]
+    L.rl_init.argtypes = [vp]
+    L.rl_boost_round.argtypes = [vp, C.POINTER(RlTree), f32p, f32p, C.POINTER(i32)]
+    L.rl_boost_rounds_async.argtypes = [vp, i32]
+    L.rl_sync.argtypes = [vp]
+    L.rl_finish.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.rl_num_trees.argtypes = [vp, C.POINTER(i32)]
+    L.rl_get_tree.argtypes = [vp, i32, C.POINTER(RlTree)]
+    L.rl_get_round_metrics.argtypes = [vp, i32, f32p, f32p]
+    L.rl_best_validation.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_double)]
+    L.rl_predict.argtypes = [vp, vp, i64, vp]
+    L.rl_model_to_text.argtypes = [vp, C.c_char_p, i64, C.POINTER(i64)]
+    L.rl_model_from_text.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+    L.rl_model_destroy.argtypes = [vp]
+    L.rl_model_destroy.restype = None
+    L.rl_model_num_trees.argtypes = [vp, C.POINTER(i32)]
+    L.rl_model_features.argtypes = [vp, vp, i32, C.POINTER(i32)]
+    L.rl_model_predict.argtypes = [vp, vp, i64, i32, vp]
+    L.rl_dist_unique_id.argtypes = [vp]
+    L.rl_dist_init.argtypes = [vp, vp, i32, i32]
+    L.rl_bin_stride.argtypes = [vp, C.POINTER(i32)]
+    L.rl_quant_exponent.argtypes = [vp, C.POINTER(i32)]
+    L.rl_get_array.argtypes = [vp, i32, vp, i64]
+    L.rl_get_timing.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
+    L.rl_reset_timing.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise RankLibError("%s (rlhip status %d)" % (lib().rl_last_error().decode("utf-8", "replace"), rc))
+
+
+def device_count():
+    n = C.c_int32(0)
+    rc = lib().rl_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+class FlatTree:
+    """One regression tree in pre-order (root 0, left subtree first)."""
+
+    def __init__(self, cap):
+        self.cap = cap
+        self.feature = np.full(cap, -1, np.int32)
+        self.threshold = np.zeros(cap, np.float32)
+        self.left = np.full(cap, -1, np.int32)
+        self.right = np.full(cap, -1, np.int32)
+        self.output = np.zeros(cap, np.float32)
+        self.deviance = np.zeros(cap, np.float64)
+        self.count = np.zeros(cap, np.int32)
+        self.n_nodes = 0
+
+    def c(self):
+        def p(a, t):
+            return a.ctypes.data_as(C.POINTER(t))
+        return RlTree(0, self.cap, p(self.feature, C.c_int32), p(self.threshold, C.c_float), p(self.left, C.c_int32),
+                      p(self.right, C.c_int32), p(self.output, C.c_float), p(self.deviance, C.c_double),
+                      p(self.count, C.c_int32))
+
+    def trimmed(self):
+        n = self.n_nodes
+        return dict(feature=self.feature[:n].copy(), threshold=self.threshold[:n].copy(), left=self.left[:n].copy(),
+                    right=self.right[:n].copy(), output=self.output[:n].copy(), deviance=self.deviance[:n].copy(),
+                    count=self.count[:n].copy())
+
+
+class Trainer:
+    """Thin object wrapper over the rl_trainer handle (one GPU)."""
+
+    def __init__(self, n_trees=1000, n_leaves=10, learning_rate=0.1, n_threshold=256, min_leaf_support=1,
+                 early_stop_rounds=100, metric_k=10, device=0, flags=0):
+        L = lib()
+        self.p = RlParams()
+        L.rl_params_default(C.byref(self.p))
+        self.p.n_trees, self.p.n_leaves, self.p.learning_rate = n_trees, n_leaves, learning_rate
+        self.p.n_threshold, self.p.min_leaf_support, self.p.early_stop_rounds = n_threshold, min_leaf_support, early_stop_rounds
+        self.p.metric_k, self.p.device, self.p.flags = metric_k, device, flags
+        self.h = C.c_void_p()
+        check(L.rl_create(C.byref(self.p), C.byref(self.h)))
+        self.cap = max(1, 2 * n_leaves - 1)
+        self.N = self.F = self.Q = 0
+        self.Nv = 0
+        self.has_valid = False
+
+    @staticmethod
+    def _prep(X, labels, qoff, qkey, F=None):
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        if X.ndim != 2:
+            raise RankLibError("X must be [n_docs, n_features]")
+        labels = np.ascontiguousarray(labels, dtype=np.float32)
+        qoff = np.ascontiguousarray(qoff, dtype=np.int32)
+        qk = None if qkey is None else np.ascontiguousarray(qkey, dtype=np.int32)
+        return X, labels, qoff, qk
+
+    def set_train(self, X, labels, qoff, feature_ids=None, qkey=None):
+        X, labels, qoff, qk = self._prep(X, labels, qoff, qkey)
+        fid = None if feature_ids is None else np.ascontiguousarray(feature_ids, dtype=np.int32)
+        self.N, self.F = X.shape
+        self.Q = len(qoff) - 1
+        check(lib().rl_set_train(self.h, X.ctypes.data, self.N, self.F, labels.ctypes.data, qoff.ctypes.data, self.Q,
+                                 None if fid is None else fid.ctypes.data, None if qk is None else qk.ctypes.data))
+
+    def set_validation(self, X, labels, qoff, qkey=None):
+        X, labels, qoff, qk = self._prep(X, labels, qoff, qkey)
+        if X.shape[1] != self.F:
+            raise RankLibError("validation set must have the training set's feature columns")
+        self.Nv = X.shape[0]
+        check(lib().rl_set_validation(self.h, X.ctypes.data, self.Nv, labels.ctypes.data, qoff.ctypes.data,
+                                      len(qoff) - 1, None if qk is None else qk.ctypes.data))
+        self.has_valid = True
+
+    def init(self):
+        check(lib().rl_init(self.h))
+
+    def boost_round(self, want_tree=True):
+        t = FlatTree(self.cap) if want_tree else None
+        ct = t.c() if t else None
+        tm, vm, stop = C.c_float(0), C.c_float(0), C.c_int32(0)
+        check(lib().rl_boost_round(self.h, C.byref(ct) if t else None, C.byref(tm), C.byref(vm), C.byref(stop)))
+        if t:
+            t.n_nodes = ct.n_nodes
+        return t, np.float32(tm.value), (np.float32(vm.value) if self.has_valid else None), bool(stop.value)
+
+    def boost_rounds_async(self, n):
+        check(lib().rl_boost_rounds_async(self.h, n))
+
+    def sync(self):
+        check(lib().rl_sync(self.h))
+
+    def finish(self):
+        ts, vs = C.c_double(0), C.c_double(0)
+        check(lib().rl_finish(self.h, C.byref(ts), C.byref(vs)))
+        return ts.value, (vs.value if self.has_valid else None)
+
+    def num_trees(self):
+        n = C.c_int32(0)
+        check(lib().rl_num_trees(self.h, C.byref(n)))
+        return n.value
+
+    def get_tree(self, i):
+        t = FlatTree(self.cap)
+        ct = t.c()
+        check(lib().rl_get_tree(self.h, i, C.byref(ct)))
+        t.n_nodes = ct.n_nodes
+        return t
+
+    def round_metrics(self, r):
+        tm, vm = C.c_float(0), C.c_float(0)
+        check(lib().rl_get_round_metrics(self.h, r, C.byref(tm), C.byref(vm)))
+        return np.float32(tm.value), (np.float32(vm.value) if self.has_valid else None)
+
+    def best_validation(self):
+        b, s = C.c_int32(0), C.c_double(0)
+        check(lib().rl_best_validation(self.h, C.byref(b), C.byref(s)))
+        return b.value, s.value
+
+    def predict(self, X):
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        out = np.zeros(X.shape[0], np.float32)
+        check(lib().rl_predict(self.h, X.ctypes.data, X.shape[0], out.ctypes.data))
+        return out
+
+    def model_text(self):
+        need = C.c_int64(0)
+        check(lib().rl_model_to_text(self.h, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(need.value)
+        check(lib().rl_model_to_text(self.h, buf, need.value, C.byref(need)))
+        return buf.value.decode("ascii")
+
+    def bin_stride(self):
+        s = C.c_int32(0)
+        check(lib().rl_bin_stride(self.h, C.byref(s)))
+        return s.value
+
+    def quant_exponent(self):
+        e = C.c_int32(0)
+        check(lib().rl_quant_exponent(self.h, C.byref(e)))
+        return e.value
+
+    def array(self, name):
+        which = ARR[name]
+        TS = self.bin_stride()
+        shapes = {
+            "LAMBDA": ((self.N,), np.float64), "WEIGHT": ((self.N,), np.float64), "SCORE": ((self.N,), np.float64),
+            "VALID_SCORE": ((self.Nv,), np.float64), "NBINS": ((self.F,), np.int32),
+            "THRESHOLDS": ((self.F, TS), np.float32), "BINS": ((self.F, self.N), np.uint16),
+            "ROOT_COUNT": ((self.F, TS), np.int32), "ROOT_SUM": ((self.F, TS), np.float64),
+            "QUANT": ((self.N,), np.int64), "ROOT_SUM_FIXED": ((self.F, TS, 2), np.int64),
+            "NDCG_PER_QUERY": ((self.Q,), np.float64),
+        }
+        shape, dt = shapes[name]
+        out = np.zeros(shape, dt)
+        check(lib().rl_get_array(self.h, which, out.ctypes.data, out.nbytes))
+        return out
+
+    def timing(self, kernel):
+        ms, n, b = C.c_double(0), C.c_int64(0), C.c_double(0)
+        check(lib().rl_get_timing(self.h, KERNEL[kernel], C.byref(ms), C.byref(n), C.byref(b)))
+        return ms.value, n.value, b.value
+
+    def reset_timing(self):
+        check(lib().rl_reset_timing(self.h))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            lib().rl_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Model:
+    """A scoring-only ensemble loaded from RankLib model text (rl_model_*)."""
+
+    def __init__(self, text, device=0):
+        self.h = C.c_void_p()
+        check(lib().rl_model_from_text(text.encode("ascii"), device, C.byref(self.h)))
+
+    def num_trees(self):
+        n = C.c_int32(0)
+        check(lib().rl_model_num_trees(self.h, C.byref(n)))
+        return n.value
+
+    def features(self):
+        n = C.c_int32(0)
+        check(lib().rl_model_features(self.h, None, 0, C.byref(n)))
+        ids = np.zeros(max(1, n.value), np.int32)
+        check(lib().rl_model_features(self.h, ids.ctypes.data, n.value, C.byref(n)))
+        return ids[:n.value]
+
+    def predict_rows(self, rows):
+        """rows[:, f] holds feature ID f (column 0 unused, like DataPoint.fVals)"""
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        out = np.zeros(rows.shape[0], np.float32)
+        check(lib().rl_model_predict(self.h, rows.ctypes.data, rows.shape[0], rows.shape[1], out.ctypes.data))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            lib().rl_model_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,103 @@
+// rl_device.h -- device-side numeric helpers for the gfx950 LambdaMART kernels.
+//
+// Everything here is exact-by-construction arithmetic that the parity argument in DESIGN.md
+// relies on.  Compile with -ffp-contract=off: the reference (Java) never fuses a*b+c.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rl {
+
+typedef __int128 i128;
+typedef unsigned __int128 u128;
+
+__device__ __forceinline__ double bits2d(uint64_t u) { return __longlong_as_double((long long)u); }
+__device__ __forceinline__ uint64_t d2bits(double d) { return (uint64_t)__double_as_longlong(d); }
+
+// exp(x) for the rho of LambdaMART.java:383.  Java's StrictMath.exp is fdlibm's e_exp and Math.exp must
+// stay within 1 ulp of it; this follows the published fdlibm scheme (ln2 hi/lo argument reduction,
+// degree-5 rational remainder) so that host oracle and device agree bit for bit.
+__device__ inline double exp_fdlibm(double x)
+{
+    const double LN2_HI = bits2d(0x3fe62e42fee00000ULL), LN2_LO = bits2d(0x3dea39ef35793c76ULL);
+    const double INV_LN2 = bits2d(0x3ff71547652b82feULL);
+    const double C1 = bits2d(0x3FC555555555553EULL), C2 = bits2d(0xBF66C16C16BEBD93ULL),
+                 C3 = bits2d(0x3F11566AAF25DE2CULL), C4 = bits2d(0xBEBBBD41C5D26BF1ULL),
+                 C5 = bits2d(0x3E66376972BEA4D0ULL);
+    const uint64_t ux = d2bits(x);
+    const uint32_t top = (uint32_t)(ux >> 32) & 0x7fffffffu;
+    const bool neg = (ux >> 63) != 0;
+    if (top >= 0x40862E42u) {
+        if (top >= 0x7ff00000u) {
+            if ((ux & 0x000fffffffffffffULL) != 0) return x + x;
+            return neg ? 0.0 : x;
+        }
+        if (x > bits2d(0x40862E42FEFA39EFULL)) return bits2d(0x7ff0000000000000ULL);
+        if (x < bits2d(0xc0874910D52D3051ULL)) return 0.0;
+    }
+    double hi = 0.0, lo = 0.0;
+    int k = 0;
+    if (top > 0x3fd62e42u) {
+        if (top < 0x3FF0A2B2u) {
+            hi = x - (neg ? -LN2_HI : LN2_HI);
+            lo = neg ? -LN2_LO : LN2_LO;
+            k = neg ? -1 : 1;
+        } else {
+            k = (int)(INV_LN2 * x + (neg ? -0.5 : 0.5));
+            const double t = (double)k;
+            hi = x - t * LN2_HI;
+            lo = t * LN2_LO;
+        }
+        x = hi - lo;
+    } else if (top < 0x3e300000u) {
+        return 1.0 + x;
+    }
+    const double t = x * x;
+    const double c = x - t * (C1 + t * (C2 + t * (C3 + t * (C4 + t * C5))));
+    if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
+    double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+    if (k >= -1021) return bits2d(d2bits(y) + ((uint64_t)(uint32_t)k << 52));
+    y = bits2d(d2bits(y) + ((uint64_t)(uint32_t)(k + 1000) << 52));
+    return y * bits2d(0x0170000000000000ULL);
+}
+
+// value * 2^-e of a 128-bit fixed-point integer, rounded ONCE to nearest-even.
+__device__ inline double fixed_to_double(i128 v, int e)
+{
+    if (v == 0) return 0.0;
+    const bool neg = v < 0;
+    u128 a = neg ? (u128)(-v) : (u128)v;
+    const uint64_t ahi = (uint64_t)(a >> 64);
+    int shift = 0;
+    uint64_t top;
+    if (ahi == 0) {
+        top = (uint64_t)a;
+    } else {
+        shift = 64 - __clzll((long long)ahi);
+        top = (uint64_t)(a >> shift);
+        const u128 mask = (((u128)1) << shift) - 1;
+        if ((a & mask) != 0) top |= 1ULL;          // sticky bit keeps the single rounding correct
+    }
+    double d = (double)top;                        // 64 -> 53 bits, round to nearest even
+    d = ldexp(d, shift - e);
+    return neg ? -d : d;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// total order key of a float (monotone over all non-NaN floats, -0 < +0)
+__device__ __forceinline__ uint32_t float_key(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(uint32_t k)
+{
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+// one step of a Java `float s; s += double x;`  (LambdaMART.java:406-407)
+__device__ __forceinline__ float float_chain_step(float s, double x) { return (float)((double)s + x); }
+
+}  // namespace rl

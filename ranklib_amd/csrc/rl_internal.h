@@ -1,0 +1,93 @@
+// rl_internal.h -- shared host/device declarations of librlhip (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rlhip.h"
+
+namespace rl {
+
+constexpr int kThreads = 256;        // 4 wavefronts of 64
+constexpr int kWave = 64;
+constexpr int kLog2Chunk = 13;       // docs accumulated into one LDS histogram copy before it is flushed
+constexpr int kChunk = 1 << kLog2Chunk;
+constexpr int kPartTile = 2048;      // docs per partition tile (256 threads x 8)
+constexpr int kMaxBins = 4096;       // bin stride limit (thresholds per feature incl. MAX_VALUE)
+constexpr int kHistLdsBytes = 64 * 1024;
+constexpr int kLambdaWaveCap = 384;  // docs/query handled by the wave-per-query lambda kernel
+constexpr int kLambdaBlockCap = 5000;// docs/query handled by the block-per-query kernel
+
+// A tree node while the tree is being grown (device resident).
+// Mirrors Split + its FeatureHistogram scalars (learning/tree/Split.java:22-38,
+// learning/tree/FeatureHistogram.java:36-44).
+struct NodeRec {
+    int32_t start, count;    // sample range [start, start+count) in index buffer `buf`
+    int32_t buf, parent;
+    int32_t left, right;     // node ids, -1 while a leaf
+    int32_t best_f, best_t;  // best split of THIS node (feature index, threshold index); -1 = none
+    double  best_S;          // -1 = no admissible candidate          (FeatureHistogram.java:311)
+    double  deviance;        // Split.deviance
+    double  sum_response;    // node total of lambda, converted from the exact fixed-point total
+    double  sq_response;     // node total of lambda^2
+    long long tot_hi; unsigned long long tot_lo;   // exact 128-bit fixed-point sum of lambda
+    long long sq;            // exact fixed-point sum of lambda^2
+    float   output; int32_t pad;
+};
+
+struct TreeState {
+    int32_t n_nodes, cur, done, taken;
+    int32_t qsize, new_left, new_right, n_leaves;
+    int32_t E, E2, n_splits, error;
+    unsigned long long maxabs_bits;   // max |lambda| of the round (bit pattern, monotone for x >= 0)
+    long long root_sq;                // sum over all docs of rint(lambda^2 * 2^E2)
+    long long sq_left;                // same over the left child being built
+};
+
+// one kept tree of the ensemble, nodes in creation order
+struct TreeSlot {
+    int32_t n_nodes, pad;
+};
+
+struct Ctx {
+    int32_t N, Npad, Q, F, TS, L, MAXN, mls, k, maxChunks, nTiles, FG, numFG;
+    float lr;
+    int32_t rank, n_ranks;
+    // static per data set
+    const uint16_t *bins;   // [F][Npad]
+    const float *thr;       // [F][TS]
+    const int32_t *nthr;    // [F]
+    const int32_t *feature_ids;
+    const float *labels;    // [N]
+    const int32_t *qoff;    // [Q+1]
+    const double *ideal0, *ideal1;  // [Q] ideal DCG used by swapChange in round 0 / later (NDCGScorer cache quirk)
+    const double *disc;     // discount table, >= maxq+2 entries
+    // per round
+    double *scores, *lambda, *weight, *ndcg_q;
+    long long *q, *r;
+    int32_t *idx[2];
+    NodeRec *nodes;
+    TreeState *st;
+    int32_t *queue;
+    long long *cum_hi; unsigned long long *cum_lo; int32_t *cum_cnt;   // [MAXN][F][TS] cumulative
+    long long *part_sum; int32_t *part_cnt;                            // [maxChunks][F][TS]
+    double *fb_S; int32_t *fb_t;                                       // [2][F]
+    int32_t *tile_cnt;                                                 // [nTiles]
+    int32_t *leaf_node, *leaf_start;                                   // [MAXN], [MAXN+1]
+    float *round_metric;                                               // [n_trees][2]
+};
+
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+
+}  // namespace rl
+
+#define RL_HIP(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return rl::fail(RL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " at " + \
+                                            __FILE__ + ":" + std::to_string(__LINE__));              \
+    } while (0)

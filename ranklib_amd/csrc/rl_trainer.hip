@@ -1,0 +1,970 @@
+// rl_trainer.hip -- host orchestration + C ABI of librlhip.so (see include/rlhip.h).
+//
+// One handle = one GPU = one HIP stream.  After rl_init everything a boosting round needs is resident in
+// HBM; a round is a fixed sequence of kernel launches with NO host synchronisation inside it: the tree is
+// grown by device-side state (TreeState / NodeRec), the host only enqueues "one more split step" L-1 times.
+//
+// There is no CPU fallback anywhere in this file: without a gfx950 device rl_create fails with
+// RL_ERR_NO_DEVICE.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+
+#include "rl_internal.h"
+#include "rl_device.h"
+#include "rl_kernels_init.inc"
+#include "rl_kernels_round.inc"
+#include "rl_model.h"
+
+namespace rl {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+struct DevPool {
+    std::vector<void *> ptrs;
+    template <typename T> hipError_t alloc(T **p, size_t n)
+    {
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
+        if (e == hipSuccess) { ptrs.push_back(q); *p = (T *)q; }
+        return e;
+    }
+    void release(void *p)
+    {
+        for (auto &q : ptrs) if (q == p) { (void)hipFree(q); q = nullptr; }
+    }
+    ~DevPool() { for (void *q : ptrs) if (q) (void)hipFree(q); }
+};
+
+struct DataSet {
+    int64_t N = 0; int32_t Q = 0;
+    std::vector<float> labels; std::vector<int32_t> qoff, qkey; bool has_key = false;
+    float *d_X = nullptr;          // row-major rows [N][F]
+    float *d_labels = nullptr; int32_t *d_qoff = nullptr; double *d_ideal0 = nullptr, *d_ideal1 = nullptr;
+    double *d_scores = nullptr, *d_ndcg = nullptr;
+    int32_t *d_qsmall = nullptr, *d_qbig = nullptr; int32_t n_small = 0, n_big = 0; bool all_small = false;
+    int32_t maxq = 0;
+};
+
+struct TimingSlot { double ms = 0; int64_t launches = 0; double bytes = 0; };
+
+}  // namespace rl
+
+using namespace rl;
+
+struct rl_trainer {
+    rl_params p;
+    int32_t F = 0;
+    std::vector<int32_t> feature_ids;
+    DataSet tr, va;
+    bool has_train = false, has_valid = false, inited = false, finished = false;
+    hipStream_t stream = nullptr;
+    DevPool pool;
+    Ctx ctx;
+    EnsTree ens;
+    int32_t round = 0;          // rounds enqueued so far
+    int32_t synced_rounds = 0;
+    int32_t n_kept = 0;         // trees kept after rollback (== round until rl_finish)
+    int32_t best_round = 2147483647 - 2;     // LambdaMART.bestModelOnValidation  LambdaMART.java:50
+    double best_score = 0.0;                 // Ranker.bestScoreOnValidationData  Ranker.java:43
+    std::vector<float> h_metrics;            // [round][2]
+    std::vector<HostTree> trees;             // host copies (pre-order), fetched lazily
+    float *d_final_f = nullptr; double *d_final_d = nullptr, *d_mean = nullptr;
+    float *d_vmetric = nullptr;
+    // timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending[RL_KERNEL_COUNT_];
+    std::vector<double> ev_bytes[RL_KERNEL_COUNT_];
+    std::vector<hipEvent_t> ev_free;
+    TimingSlot timing[RL_KERNEL_COUNT_];
+    // distributed
+    int32_t rank = 0, n_ranks = 1;
+};
+
+namespace rl {
+
+static int check_trainer(const rl_trainer *t) { return t ? RL_OK : fail(RL_ERR_INVALID, "null trainer handle"); }
+
+// ---- host-side NDCG constants ------------------------------------------------------------------
+static double discount_of(int i) { return 1.0 / (std::log((double)(i + 2)) / std::log(2.0)); }   // DCGScorer.java:26
+
+static double ideal_dcg(const float *labels, int n, int topk, const std::vector<double> &disc)
+{   // NDCGScorer.getIdealDCG (:167-174)
+    std::vector<int> rel(n);
+    for (int i = 0; i < n; i++) rel[i] = (int)labels[i];
+    std::sort(rel.begin(), rel.end(), [](int a, int b) { return a > b; });
+    double dcg = 0;
+    for (int i = 0; i < topk; i++) dcg += (double)((1 << rel[i]) - 1) * disc[i];
+    return dcg;
+}
+
+static int validate_dataset(const float *X, int64_t n, int32_t F, const float *labels, const int32_t *qoff, int32_t Q)
+{
+    if (!X || !labels || !qoff) return fail(RL_ERR_INVALID, "null data pointer");
+    if (n <= 0 || Q <= 0 || F <= 0) return fail(RL_ERR_INVALID, "There are no training samples / features");
+    if (n >= (int64_t)2147483647 - 4096) return fail(RL_ERR_UNSUPPORTED, "more than 2^31 documents per GPU");
+    if (qoff[0] != 0 || (int64_t)qoff[Q] != n) return fail(RL_ERR_INVALID, "qoff must start at 0 and end at n_docs");
+    for (int32_t q = 0; q < Q; q++)
+        if (qoff[q + 1] <= qoff[q]) return fail(RL_ERR_INVALID, "qoff must be strictly increasing (empty ranked list)");
+    for (int64_t i = 0; i < n; i++) {
+        if (!(labels[i] >= 0)) return fail(RL_ERR_INVALID, "Relevance label cannot be negative. System will now exit.");  // DataPoint.java:71-73
+        if (labels[i] > 30.f) return fail(RL_ERR_UNSUPPORTED, "relevance label above 30 (gain 2^l-1 overflows int, DCGScorer.java:138)");
+    }
+    return RL_OK;
+}
+
+static int load_dataset(rl_trainer *t, DataSet &d, const float *X, int64_t n, const float *labels, const int32_t *qoff,
+                        int32_t Q, const int32_t *qkey)
+{
+    d.N = n; d.Q = Q;
+    d.labels.assign(labels, labels + n);
+    d.qoff.assign(qoff, qoff + Q + 1);
+    d.has_key = qkey != nullptr;
+    if (qkey) d.qkey.assign(qkey, qkey + Q); else d.qkey.clear();
+    d.maxq = 0;
+    for (int32_t q = 0; q < Q; q++) d.maxq = std::max(d.maxq, qoff[q + 1] - qoff[q]);
+    if (d.maxq > kLambdaBlockCap)
+        return fail(RL_ERR_UNSUPPORTED, "a ranked list with more than " + std::to_string(kLambdaBlockCap) + " documents");
+    RL_HIP(t->pool.alloc(&d.d_X, (size_t)n * t->F));
+    RL_HIP(hipMemcpy(d.d_X, X, (size_t)n * t->F * sizeof(float), hipMemcpyHostToDevice));
+    return RL_OK;
+}
+
+static int upload_query_side(rl_trainer *t, DataSet &d, const std::vector<double> &ideal0, const std::vector<double> &ideal1)
+{
+    RL_HIP(t->pool.alloc(&d.d_labels, (size_t)d.N));
+    RL_HIP(hipMemcpy(d.d_labels, d.labels.data(), d.N * sizeof(float), hipMemcpyHostToDevice));
+    RL_HIP(t->pool.alloc(&d.d_qoff, (size_t)d.Q + 1));
+    RL_HIP(hipMemcpy(d.d_qoff, d.qoff.data(), ((size_t)d.Q + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    RL_HIP(t->pool.alloc(&d.d_ideal0, (size_t)d.Q));
+    RL_HIP(t->pool.alloc(&d.d_ideal1, (size_t)d.Q));
+    RL_HIP(hipMemcpy(d.d_ideal0, ideal0.data(), d.Q * sizeof(double), hipMemcpyHostToDevice));
+    RL_HIP(hipMemcpy(d.d_ideal1, ideal1.data(), d.Q * sizeof(double), hipMemcpyHostToDevice));
+    RL_HIP(t->pool.alloc(&d.d_scores, (size_t)d.N));
+    RL_HIP(hipMemset(d.d_scores, 0, d.N * sizeof(double)));                // modelScores = 0  LambdaMART.java:86
+    RL_HIP(t->pool.alloc(&d.d_ndcg, (size_t)d.Q));
+    std::vector<int32_t> small, big;
+    for (int32_t q = 0; q < d.Q; q++) ((d.qoff[q + 1] - d.qoff[q]) <= kLambdaWaveCap ? small : big).push_back(q);
+    d.n_small = (int32_t)small.size(); d.n_big = (int32_t)big.size();
+    d.all_small = big.empty();
+    RL_HIP(t->pool.alloc(&d.d_qsmall, small.size()));
+    RL_HIP(t->pool.alloc(&d.d_qbig, big.size()));
+    if (!small.empty()) RL_HIP(hipMemcpy(d.d_qsmall, small.data(), small.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (!big.empty()) RL_HIP(hipMemcpy(d.d_qbig, big.data(), big.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return RL_OK;
+}
+
+static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+// ---- timing helpers ----------------------------------------------------------------------------
+static hipEvent_t take_event(rl_trainer *t)
+{
+    if (!t->ev_free.empty()) { hipEvent_t e = t->ev_free.back(); t->ev_free.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+struct ScopedTiming {
+    rl_trainer *t; int which; hipEvent_t a = nullptr, b = nullptr; bool on;
+    ScopedTiming(rl_trainer *t_, int which_, double bytes) : t(t_), which(which_), on((t_->p.flags & RL_FLAG_TIMING) != 0)
+    {
+        if (!on) return;
+        a = take_event(t); b = take_event(t);
+        (void)hipEventRecord(a, t->stream);
+        t->ev_bytes[which].push_back(bytes);
+    }
+    ~ScopedTiming() { if (on) { (void)hipEventRecord(b, t->stream); t->ev_pending[which].push_back({a, b}); } }
+};
+static void collect_timing(rl_trainer *t)
+{
+    for (int w = 0; w < RL_KERNEL_COUNT_; w++) {
+        for (size_t i = 0; i < t->ev_pending[w].size(); i++) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, t->ev_pending[w][i].first, t->ev_pending[w][i].second) == hipSuccess) {
+                t->timing[w].ms += ms; t->timing[w].launches++; t->timing[w].bytes += t->ev_bytes[w][i];
+            }
+            t->ev_free.push_back(t->ev_pending[w][i].first); t->ev_free.push_back(t->ev_pending[w][i].second);
+        }
+        t->ev_pending[w].clear(); t->ev_bytes[w].clear();
+    }
+}
+
+// ---- per-query kernels on a data set -------------------------------------------------------------
+static int launch_ndcg(rl_trainer *t, DataSet &d, const double *scores, double *out)
+{
+    NdcgArgs a{scores, d.d_labels, d.d_qoff, d.d_ideal1, t->ctx.disc, out, d.Q, t->p.metric_k};
+    if (d.n_small > 0)
+        hipLaunchKernelGGL(k_ndcg_wave, dim3((d.n_small + 3) / 4), dim3(kThreads), 4 * kLambdaWaveCap * 12, t->stream, a,
+                           d.all_small ? (const int *)nullptr : d.d_qsmall, d.n_small);
+    if (d.n_big > 0)
+        hipLaunchKernelGGL(k_ndcg_block, dim3(d.n_big), dim3(kThreads), kLambdaBlockCap * 12, t->stream, a, d.d_qbig, d.n_big);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+static int enqueue_round(rl_trainer *t)
+{
+    Ctx &c = t->ctx;
+    hipStream_t s = t->stream;
+    const int m = t->round;
+    // round scalars
+    RL_HIP(hipMemsetAsync(&c.st->maxabs_bits, 0, sizeof(unsigned long long) + 2 * sizeof(long long), s));
+    {   // K1 lambdas
+        ScopedTiming tm(t, RL_KERNEL_LAMBDA, (double)c.N * 28.0);
+        if (t->tr.n_small > 0)
+            hipLaunchKernelGGL(k_lambda_wave, dim3((t->tr.n_small + 3) / 4), dim3(kThreads), 4 * kLambdaWaveCap * 32, s, c, m,
+                               t->tr.all_small ? (const int *)nullptr : t->tr.d_qsmall, t->tr.n_small);
+        if (t->tr.n_big > 0)
+            hipLaunchKernelGGL(k_lambda_block, dim3(t->tr.n_big), dim3(kThreads), kLambdaBlockCap * 32, s, c, m, t->tr.d_qbig, t->tr.n_big);
+    }
+    hipLaunchKernelGGL(k_quantize, dim3(std::min(2048, (c.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, c);
+    const size_t hist_lds = (size_t)c.FG * c.TS * 12;
+    const size_t fin_lds = (size_t)c.TS * 20;
+    const int rootChunks = (c.N + kChunk - 1) / kChunk;
+    {   // K2 root histogram
+        ScopedTiming tm(t, RL_KERNEL_HIST_ROOT, (double)c.N * ((double)c.F * 2.0 + 8.0));
+        hipLaunchKernelGGL(k_hist<true>, dim3(c.numFG, rootChunks), dim3(kThreads), hist_lds, s, c);
+    }
+    hipLaunchKernelGGL(k_hist_finish<true>, dim3(c.F), dim3(kThreads), fin_lds, s, c);
+    hipLaunchKernelGGL(k_select, dim3(1), dim3(64), 0, s, c, 1);
+    const int steps = c.L - 1;
+    for (int it = 0; it < steps; it++) {
+        hipLaunchKernelGGL(k_part_count, dim3(c.nTiles), dim3(kThreads), 0, s, c);
+        hipLaunchKernelGGL(k_part_scatter, dim3(c.nTiles), dim3(kThreads), 0, s, c);
+        {
+            ScopedTiming tm(t, RL_KERNEL_HIST_NODE, 0.0);
+            hipLaunchKernelGGL(k_hist<false>, dim3(c.numFG, c.maxChunks), dim3(kThreads), hist_lds, s, c);
+        }
+        hipLaunchKernelGGL(k_hist_finish<false>, dim3(c.F), dim3(kThreads), fin_lds, s, c);
+        hipLaunchKernelGGL(k_select, dim3(1), dim3(64), 0, s, c, 0);
+    }
+    hipLaunchKernelGGL(k_leaf_table, dim3(1), dim3(64), 0, s, c);
+    hipLaunchKernelGGL(k_leaf_chain, dim3(c.L), dim3(64), 0, s, c);
+    hipLaunchKernelGGL(k_score_update, dim3(std::min(4096, (c.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, c);
+    hipLaunchKernelGGL(k_export_tree, dim3(1), dim3(kThreads), 0, s, c, t->ens, m);
+    RL_HIP(hipGetLastError());
+    // per-round training metric (LambdaMART.java:216)
+    int rc = launch_ndcg(t, t->tr, c.scores, t->tr.d_ndcg);
+    if (rc != RL_OK) return rc;
+    hipLaunchKernelGGL(k_float_mean, dim3(1), dim3(64), 0, s, (const double *)t->tr.d_ndcg, t->tr.Q, c.round_metric + 2 * (size_t)m);
+    if (t->has_valid) {   // :228-237
+        hipLaunchKernelGGL(k_valid_update, dim3(std::min<int64_t>(4096, (t->va.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                           t->ens, c.MAXN, m, (const float *)t->va.d_X, (int)t->va.N, c.F, c.lr, t->va.d_scores);
+        rc = launch_ndcg(t, t->va, t->va.d_scores, t->va.d_ndcg);
+        if (rc != RL_OK) return rc;
+        hipLaunchKernelGGL(k_float_mean, dim3(1), dim3(64), 0, s, (const double *)t->va.d_ndcg, t->va.Q, c.round_metric + 2 * (size_t)m + 1);
+    }
+    RL_HIP(hipGetLastError());
+    t->round = m + 1;
+    t->n_kept = t->round;
+    return RL_OK;
+}
+
+static int sync_rounds(rl_trainer *t)
+{
+    RL_HIP(hipStreamSynchronize(t->stream));
+    collect_timing(t);
+    TreeState st;
+    RL_HIP(hipMemcpy(&st, t->ctx.st, sizeof(st), hipMemcpyDeviceToHost));
+    if (st.error) return fail(RL_ERR_HIP, "device tree growth ran out of node slots (internal error)");
+    if (t->round > t->synced_rounds) {
+        t->h_metrics.resize((size_t)t->round * 2);
+        RL_HIP(hipMemcpy(t->h_metrics.data() + 2 * (size_t)t->synced_rounds, t->ctx.round_metric + 2 * (size_t)t->synced_rounds,
+                         (size_t)(t->round - t->synced_rounds) * 2 * sizeof(float), hipMemcpyDeviceToHost));
+        t->synced_rounds = t->round;
+    }
+    return RL_OK;
+}
+
+static int fetch_tree(const rl_trainer *tc, int i, HostTree &out)
+{
+    rl_trainer *t = const_cast<rl_trainer *>(tc);
+    if ((int)t->trees.size() <= i) t->trees.resize((size_t)i + 1);
+    if (t->trees[i].n_nodes > 0) { out = t->trees[i]; return RL_OK; }
+    const int MAXN = t->ctx.MAXN;
+    int32_t nn = 0;
+    RL_HIP(hipMemcpy(&nn, t->ens.n_nodes + i, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (nn <= 0 || nn > MAXN) return fail(RL_ERR_STATE, "tree " + std::to_string(i) + " has not been built");
+    std::vector<int32_t> fi(nn), le(nn), ri(nn), cn(nn);
+    std::vector<float> th(nn), ou(nn);
+    std::vector<double> dv(nn);
+    const size_t o = (size_t)i * MAXN;
+    RL_HIP(hipMemcpy(fi.data(), t->ens.feat_idx + o, nn * sizeof(int32_t), hipMemcpyDeviceToHost));
+    RL_HIP(hipMemcpy(le.data(), t->ens.left + o, nn * sizeof(int32_t), hipMemcpyDeviceToHost));
+    RL_HIP(hipMemcpy(ri.data(), t->ens.right + o, nn * sizeof(int32_t), hipMemcpyDeviceToHost));
+    RL_HIP(hipMemcpy(cn.data(), t->ens.count + o, nn * sizeof(int32_t), hipMemcpyDeviceToHost));
+    RL_HIP(hipMemcpy(th.data(), t->ens.thr + o, nn * sizeof(float), hipMemcpyDeviceToHost));
+    RL_HIP(hipMemcpy(ou.data(), t->ens.out + o, nn * sizeof(float), hipMemcpyDeviceToHost));
+    RL_HIP(hipMemcpy(dv.data(), t->ens.deviance + o, nn * sizeof(double), hipMemcpyDeviceToHost));
+    HostTree h;
+    h.weight = t->p.learning_rate;
+    // creation order -> pre-order (root, left subtree, right subtree)
+    std::vector<int> stack{0};
+    std::vector<int> order, newid(nn, -1);
+    while (!stack.empty()) {
+        const int x = stack.back(); stack.pop_back();
+        newid[x] = (int)order.size(); order.push_back(x);
+        if (fi[x] != -1) { stack.push_back(ri[x]); stack.push_back(le[x]); }
+    }
+    h.n_nodes = (int)order.size();
+    for (int x : order) {
+        const bool leaf = fi[x] == -1;
+        h.feature.push_back(leaf ? -1 : t->feature_ids[fi[x]]);
+        h.threshold.push_back(th[x]);
+        h.left.push_back(leaf ? -1 : newid[le[x]]);
+        h.right.push_back(leaf ? -1 : newid[ri[x]]);
+        h.output.push_back(ou[x]);
+        h.deviance.push_back(dv[x]);
+        h.count.push_back(cn[x]);
+    }
+    t->trees[i] = h;
+    out = h;
+    return RL_OK;
+}
+
+__global__ void k_debug_root_sum(const Ctx c, double *out, long long *out_fixed)
+{
+    const int f = blockIdx.x;
+    for (int t = threadIdx.x; t < c.nthr[f]; t += blockDim.x) {
+        const size_t o = (size_t)f * c.TS + t;
+        if (out) out[o] = fixed_to_double(make_i128(c.cum_hi[o], c.cum_lo[o]), c.st->E);
+        if (out_fixed) { out_fixed[2 * o] = c.cum_hi[o]; out_fixed[2 * o + 1] = (long long)c.cum_lo[o]; }
+    }
+}
+
+}  // namespace rl
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int rl_abi_version(void) { return RLHIP_ABI_VERSION; }
+const char *rl_last_error(void) { return g_err.c_str(); }
+
+int rl_device_count(int32_t *n)
+{
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { if (n) *n = 0; return fail(RL_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    if (n) *n = c;
+    return RL_OK;
+}
+
+void rl_params_default(rl_params *p)
+{   // learning/tree/LambdaMART.java:37-42
+    if (!p) return;
+    p->n_trees = 1000; p->n_leaves = 10; p->n_threshold = 256; p->min_leaf_support = 1; p->early_stop_rounds = 100;
+    p->learning_rate = 0.1F; p->metric = RL_METRIC_NDCG; p->metric_k = 10; p->device = 0; p->flags = 0;
+}
+
+int rl_create(const rl_params *p, rl_trainer **out)
+{
+    if (!p || !out) return fail(RL_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (p->metric != RL_METRIC_NDCG) return fail(RL_ERR_UNSUPPORTED, "only NDCG@k is built (SURVEY.md 8f)");
+    if (p->metric_k < 1) return fail(RL_ERR_UNSUPPORTED, "NDCG@k needs k >= 1");
+    if (p->n_trees < 1) return fail(RL_ERR_INVALID, "n_trees must be >= 1");
+    if (p->n_leaves == -1) return fail(RL_ERR_UNSUPPORTED, "unlimited leaves (-leaf -1) is not built yet");
+    if (p->n_leaves < 1) return fail(RL_ERR_INVALID, "n_leaves must be >= 1");
+    if (p->min_leaf_support < 1) return fail(RL_ERR_INVALID, "min_leaf_support must be >= 1");
+    if (p->n_threshold != -1 && (p->n_threshold < 1 || p->n_threshold + 1 > kMaxBins))
+        return fail(RL_ERR_UNSUPPORTED, "n_threshold must be -1 or in [1," + std::to_string(kMaxBins - 1) + "]");
+    if (p->flags & RL_FLAG_FAST_LEAF) return fail(RL_ERR_UNSUPPORTED, "RL_FLAG_FAST_LEAF is not built yet");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(RL_ERR_NO_DEVICE, "no HIP device visible: librlhip has no CPU fallback");
+    if (p->device < 0 || p->device >= ndev) return fail(RL_ERR_INVALID, "device ordinal out of range");
+    RL_HIP(hipSetDevice(p->device));
+    hipDeviceProp_t prop;
+    RL_HIP(hipGetDeviceProperties(&prop, p->device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(RL_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", librlhip is built for gfx950 only");
+    std::unique_ptr<rl_trainer> t(new rl_trainer());
+    t->p = *p;
+    memset(&t->ctx, 0, sizeof(t->ctx));
+    memset(&t->ens, 0, sizeof(t->ens));
+    RL_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    RL_HIP(hipFuncSetAttribute((const void *)k_lambda_block, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaBlockCap * 32));
+    RL_HIP(hipFuncSetAttribute((const void *)k_lambda_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kLambdaWaveCap * 32));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
+    RL_HIP(hipFuncSetAttribute((const void *)k_ndcg_block, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaBlockCap * 12));
+    *out = t.release();
+    return RL_OK;
+}
+
+void rl_destroy(rl_trainer *t)
+{
+    if (!t) return;
+    (void)hipSetDevice(t->p.device);
+    if (t->stream) { (void)hipStreamSynchronize(t->stream); }
+    for (int w = 0; w < RL_KERNEL_COUNT_; w++)
+        for (auto &pr : t->ev_pending[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto e : t->ev_free) (void)hipEventDestroy(e);
+    if (t->stream) (void)hipStreamDestroy(t->stream);
+    delete t;
+}
+
+int rl_set_train(rl_trainer *t, const float *X, int64_t n_docs, int32_t n_features, const float *labels, const int32_t *qoff,
+                 int32_t n_queries, const int32_t *feature_ids, const int32_t *qkey)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    if (t->has_train) return fail(RL_ERR_STATE, "training set already set");
+    int rc = validate_dataset(X, n_docs, n_features, labels, qoff, n_queries);
+    if (rc) return rc;
+    RL_HIP(hipSetDevice(t->p.device));
+    t->F = n_features;
+    t->feature_ids.resize(n_features);
+    for (int f = 0; f < n_features; f++) {
+        t->feature_ids[f] = feature_ids ? feature_ids[f] : f + 1;
+        if (t->feature_ids[f] <= 0) return fail(RL_ERR_INVALID, "Cannot use feature numbering less than or equal to zero. Start your features at 1.");
+    }
+    rc = load_dataset(t, t->tr, X, n_docs, labels, qoff, n_queries, qkey);
+    if (rc) return rc;
+    t->has_train = true;
+    return RL_OK;
+}
+
+int rl_set_validation(rl_trainer *t, const float *X, int64_t n_docs, const float *labels, const int32_t *qoff, int32_t n_queries,
+                      const int32_t *qkey)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    if (!t->has_train) return fail(RL_ERR_STATE, "set the training set first");
+    if (t->inited) return fail(RL_ERR_STATE, "validation set must be set before rl_init");
+    if (t->has_valid) return fail(RL_ERR_STATE, "validation set already set");
+    int rc = validate_dataset(X, n_docs, t->F, labels, qoff, n_queries);
+    if (rc) return rc;
+    RL_HIP(hipSetDevice(t->p.device));
+    rc = load_dataset(t, t->va, X, n_docs, labels, qoff, n_queries, qkey);
+    if (rc) return rc;
+    t->has_valid = true;
+    return RL_OK;
+}
+
+int rl_init(rl_trainer *t)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    if (!t->has_train) return fail(RL_ERR_STATE, "no training set");
+    if (t->inited) return fail(RL_ERR_STATE, "rl_init called twice");
+    RL_HIP(hipSetDevice(t->p.device));
+    Ctx &c = t->ctx;
+    hipStream_t s = t->stream;
+    const int N = (int)t->tr.N, F = t->F;
+    const int Npad = (N + 127) / 128 * 128;
+    c.N = N; c.Npad = Npad; c.Q = t->tr.Q; c.F = F; c.L = t->p.n_leaves; c.MAXN = 2 * t->p.n_leaves - 1;
+    c.mls = t->p.min_leaf_support; c.k = t->p.metric_k; c.lr = t->p.learning_rate;
+    c.rank = t->rank; c.n_ranks = t->n_ranks;
+
+    // ---- K9: thresholds + bins on the device ----------------------------------------------------
+    float *Xt = nullptr;
+    RL_HIP(t->pool.alloc(&Xt, (size_t)F * Npad));
+    hipLaunchKernelGGL(k_transpose, dim3((N + 31) / 32, (F + 31) / 32), dim3(kThreads), 0, s, (const float *)t->tr.d_X, Xt, N, F, Npad);
+    const int nT = t->p.n_threshold;
+    FeatStats fs;
+    fs.limit = (nT == -1) ? kMaxBins - 1 : nT;
+    fs.HS = next_pow2(2 * (fs.limit + 2));
+    RL_HIP(t->pool.alloc(&fs.minkey, (size_t)F)); RL_HIP(t->pool.alloc(&fs.maxkey, (size_t)F));
+    RL_HIP(t->pool.alloc(&fs.set, (size_t)F * fs.HS)); RL_HIP(t->pool.alloc(&fs.nset, (size_t)F));
+    RL_HIP(t->pool.alloc(&fs.overflow, (size_t)F)); RL_HIP(t->pool.alloc(&fs.bad, (size_t)1));
+    RL_HIP(hipMemsetAsync(fs.minkey, 0xFF, F * sizeof(uint32_t), s));
+    RL_HIP(hipMemsetAsync(fs.maxkey, 0, F * sizeof(uint32_t), s));
+    RL_HIP(hipMemsetAsync(fs.set, 0, (size_t)F * fs.HS * sizeof(uint32_t), s));
+    RL_HIP(hipMemsetAsync(fs.nset, 0, F * sizeof(int32_t), s));
+    RL_HIP(hipMemsetAsync(fs.overflow, 0, F * sizeof(int32_t), s));
+    RL_HIP(hipMemsetAsync(fs.bad, 0, sizeof(int32_t), s));
+    const int slices = std::max(1, std::min(64, N / 4096));
+    hipLaunchKernelGGL(k_feat_stats, dim3(F, slices), dim3(kThreads), fs.HS * sizeof(uint32_t), s, (const float *)Xt, N, Npad, fs);
+    RL_HIP(hipGetLastError());
+    std::vector<int32_t> h_over(F);
+    int32_t h_bad = 0;
+    RL_HIP(hipStreamSynchronize(s));
+    RL_HIP(hipMemcpy(h_over.data(), fs.overflow, F * sizeof(int32_t), hipMemcpyDeviceToHost));
+    RL_HIP(hipMemcpy(&h_bad, fs.bad, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (h_bad) return fail(RL_ERR_INVALID, "non-finite feature value (resolve NaN to 0 as DataPoint.getFeatureValue does; +-Infinity is not supported)");
+    if (nT == -1)
+        for (int f = 0; f < F; f++)
+            if (h_over[f]) return fail(RL_ERR_UNSUPPORTED, "-tc -1 with more than " + std::to_string(kMaxBins - 1) + " distinct values in a feature");
+    const int TS0 = fs.limit + 1;
+    float *thr0 = nullptr; int32_t *d_nthr = nullptr;
+    RL_HIP(t->pool.alloc(&thr0, (size_t)F * TS0)); RL_HIP(t->pool.alloc(&d_nthr, (size_t)F));
+    hipLaunchKernelGGL(k_thresholds, dim3(F), dim3(kThreads), fs.HS * sizeof(uint32_t), s, fs, nT == -1 ? fs.limit : nT, TS0, thr0, d_nthr);
+    RL_HIP(hipGetLastError());
+    std::vector<int32_t> h_nthr(F);
+    RL_HIP(hipStreamSynchronize(s));
+    RL_HIP(hipMemcpy(h_nthr.data(), d_nthr, F * sizeof(int32_t), hipMemcpyDeviceToHost));
+    int TS = 2;
+    for (int f = 0; f < F; f++) TS = std::max(TS, h_nthr[f]);
+    c.TS = TS;
+    float *d_thr = nullptr;
+    RL_HIP(t->pool.alloc(&d_thr, (size_t)F * TS));
+    RL_HIP(hipMemsetAsync(d_thr, 0, (size_t)F * TS * sizeof(float), s));
+    RL_HIP(hipMemcpy2DAsync(d_thr, TS * sizeof(float), thr0, TS0 * sizeof(float), TS * sizeof(float), F, hipMemcpyDeviceToDevice, s));
+    c.thr = d_thr; c.nthr = d_nthr;
+    if ((size_t)TS * 12 > (size_t)kHistLdsBytes) return fail(RL_ERR_UNSUPPORTED, "too many threshold candidates for the LDS histogram");
+    c.FG = std::max(1, std::min(F, (int)(kHistLdsBytes / ((size_t)TS * 12))));
+    if (c.FG > 16) c.FG = 16;
+    c.numFG = (F + c.FG - 1) / c.FG;
+
+    uint16_t *d_bins = nullptr;
+    RL_HIP(t->pool.alloc(&d_bins, (size_t)F * Npad));
+    RL_HIP(hipMemsetAsync(d_bins, 0, (size_t)F * Npad * sizeof(uint16_t), s));
+    c.bins = d_bins;
+    c.maxChunks = (N + kChunk - 1) / kChunk;
+    c.nTiles = (N + kPartTile - 1) / kPartTile;
+    RL_HIP(t->pool.alloc(&c.cum_hi, (size_t)c.MAXN * F * TS));
+    RL_HIP(t->pool.alloc(&c.cum_lo, (size_t)c.MAXN * F * TS));
+    RL_HIP(t->pool.alloc(&c.cum_cnt, (size_t)c.MAXN * F * TS));
+    RL_HIP(hipMemsetAsync(c.cum_cnt, 0, (size_t)F * TS * sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_binning, dim3(F, slices), dim3(kThreads), (size_t)TS * 8, s, (const float *)Xt, N, Npad, TS, (const float *)d_thr,
+                       (const int32_t *)d_nthr, d_bins, c.cum_cnt);
+    hipLaunchKernelGGL(k_cumulate_counts, dim3(F), dim3(64), 0, s, TS, (const int32_t *)d_nthr, c.cum_cnt);
+    RL_HIP(hipGetLastError());
+    RL_HIP(hipStreamSynchronize(s));
+    t->pool.release(Xt); t->pool.release(thr0); t->pool.release(fs.set);
+
+    // ---- query side: ideal DCGs with the qid-keyed cache quirk (NDCGScorer.java:114-122,134-143) --
+    int maxq = std::max(t->tr.maxq, t->has_valid ? t->va.maxq : 0);
+    std::vector<double> disc((size_t)maxq + 2);
+    for (size_t i = 0; i < disc.size(); i++) disc[i] = discount_of((int)i);
+    double *d_disc = nullptr;
+    RL_HIP(t->pool.alloc(&d_disc, disc.size()));
+    RL_HIP(hipMemcpy(d_disc, disc.data(), disc.size() * sizeof(double), hipMemcpyHostToDevice));
+    c.disc = d_disc;
+    {
+        std::map<int64_t, double> cache;
+        auto run = [&](DataSet &d, int64_t anon_base, std::vector<double> &own, std::vector<double> &cached) {
+            own.resize(d.Q); cached.resize(d.Q);
+            for (int q = 0; q < d.Q; q++) {
+                const int n = d.qoff[q + 1] - d.qoff[q];
+                const int size = std::min(n, t->p.metric_k);
+                own[q] = ideal_dcg(d.labels.data() + d.qoff[q], n, size, disc);
+                const int64_t key = d.has_key ? (int64_t)d.qkey[q] : anon_base + q;
+                auto it = cache.find(key);
+                if (it == cache.end()) it = cache.emplace(key, own[q]).first;   // score() fills the cache in list order
+                cached[q] = it->second;
+            }
+        };
+        std::vector<double> own, cached;
+        run(t->tr, (int64_t)1 << 40, own, cached);
+        int rc = upload_query_side(t, t->tr, own, cached);
+        if (rc) return rc;
+        if (t->has_valid) {
+            run(t->va, (int64_t)1 << 41, own, cached);
+            rc = upload_query_side(t, t->va, own, cached);
+            if (rc) return rc;
+        }
+    }
+    c.labels = t->tr.d_labels; c.qoff = t->tr.d_qoff; c.ideal0 = t->tr.d_ideal0; c.ideal1 = t->tr.d_ideal1;
+    c.scores = t->tr.d_scores; c.ndcg_q = t->tr.d_ndcg;
+    int32_t *d_fid = nullptr;
+    RL_HIP(t->pool.alloc(&d_fid, (size_t)F));
+    RL_HIP(hipMemcpy(d_fid, t->feature_ids.data(), F * sizeof(int32_t), hipMemcpyHostToDevice));
+    c.feature_ids = d_fid;
+
+    // ---- per-round state -------------------------------------------------------------------------
+    RL_HIP(t->pool.alloc(&c.lambda, (size_t)N)); RL_HIP(t->pool.alloc(&c.weight, (size_t)N));
+    RL_HIP(t->pool.alloc(&c.q, (size_t)N)); RL_HIP(t->pool.alloc(&c.r, (size_t)N));
+    RL_HIP(t->pool.alloc(&c.idx[0], (size_t)N)); RL_HIP(t->pool.alloc(&c.idx[1], (size_t)N));
+    RL_HIP(t->pool.alloc(&c.nodes, (size_t)c.MAXN + 2)); RL_HIP(t->pool.alloc(&c.st, (size_t)1));
+    RL_HIP(hipMemset(c.st, 0, sizeof(TreeState)));
+    RL_HIP(hipMemset(c.nodes, 0, ((size_t)c.MAXN + 2) * sizeof(NodeRec)));
+    RL_HIP(t->pool.alloc(&c.queue, (size_t)c.MAXN + 2));
+    RL_HIP(t->pool.alloc(&c.part_sum, (size_t)c.maxChunks * F * TS)); RL_HIP(t->pool.alloc(&c.part_cnt, (size_t)c.maxChunks * F * TS));
+    RL_HIP(t->pool.alloc(&c.fb_S, (size_t)2 * F)); RL_HIP(t->pool.alloc(&c.fb_t, (size_t)2 * F));
+    RL_HIP(t->pool.alloc(&c.tile_cnt, (size_t)c.nTiles));
+    RL_HIP(t->pool.alloc(&c.leaf_node, (size_t)c.MAXN + 1)); RL_HIP(t->pool.alloc(&c.leaf_start, (size_t)c.MAXN + 2));
+    RL_HIP(t->pool.alloc(&c.round_metric, (size_t)2 * t->p.n_trees));
+    RL_HIP(hipMemset(c.round_metric, 0, (size_t)2 * t->p.n_trees * sizeof(float)));
+    RL_HIP(hipMemset(c.lambda, 0, N * sizeof(double))); RL_HIP(hipMemset(c.weight, 0, N * sizeof(double)));
+    // ensemble
+    const size_t en = (size_t)t->p.n_trees * c.MAXN;
+    RL_HIP(t->pool.alloc(&t->ens.feat_idx, en)); RL_HIP(t->pool.alloc(&t->ens.thr, en));
+    RL_HIP(t->pool.alloc(&t->ens.left, en)); RL_HIP(t->pool.alloc(&t->ens.right, en));
+    RL_HIP(t->pool.alloc(&t->ens.out, en)); RL_HIP(t->pool.alloc(&t->ens.count, en)); RL_HIP(t->pool.alloc(&t->ens.deviance, en));
+    RL_HIP(t->pool.alloc(&t->ens.n_nodes, (size_t)t->p.n_trees));
+    RL_HIP(hipMemset(t->ens.n_nodes, 0, t->p.n_trees * sizeof(int32_t)));
+    RL_HIP(t->pool.alloc(&t->d_mean, (size_t)2));
+    RL_HIP(hipDeviceSynchronize());
+    t->inited = true;
+    return RL_OK;
+}
+
+int rl_boost_round(rl_trainer *t, rl_tree *out, float *train_metric, float *valid_metric, int32_t *stop)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    if (!t->inited) return fail(RL_ERR_STATE, "rl_init has not been called");
+    if (t->finished) return fail(RL_ERR_STATE, "rl_finish has been called");
+    if (t->round >= t->p.n_trees) return fail(RL_ERR_STATE, "all n_trees rounds are done");
+    RL_HIP(hipSetDevice(t->p.device));
+    const int m = t->round;
+    int rc = enqueue_round(t);
+    if (rc) return rc;
+    rc = sync_rounds(t);
+    if (rc) return rc;
+    if (train_metric) *train_metric = t->h_metrics[2 * (size_t)m];
+    if (t->has_valid) {
+        const float vm = t->h_metrics[2 * (size_t)m + 1];
+        if (valid_metric) *valid_metric = vm;
+        const double score = vm;                                     // LambdaMART.java:237-243
+        if (score > t->best_score) { t->best_score = score; t->best_round = t->round - 1; }
+    }
+    if (stop) *stop = (m - t->best_round > t->p.early_stop_rounds) ? 1 : 0;      // :248
+    if (out) return rl_get_tree(t, m, out);
+    return RL_OK;
+}
+
+int rl_boost_rounds_async(rl_trainer *t, int32_t n)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    if (!t->inited) return fail(RL_ERR_STATE, "rl_init has not been called");
+    if (t->has_valid) return fail(RL_ERR_STATE, "asynchronous rounds cannot honour early stopping; use rl_boost_round");
+    if (t->round + n > t->p.n_trees) return fail(RL_ERR_STATE, "more rounds than n_trees");
+    RL_HIP(hipSetDevice(t->p.device));
+    for (int i = 0; i < n; i++) { int rc = enqueue_round(t); if (rc) return rc; }
+    return RL_OK;
+}
+
+int rl_sync(rl_trainer *t)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    if (!t->inited) return fail(RL_ERR_STATE, "rl_init has not been called");
+    RL_HIP(hipSetDevice(t->p.device));
+    return sync_rounds(t);
+}
+
+static int final_score(rl_trainer *t, DataSet &d, double *out)
+{
+    hipStream_t s = t->stream;
+    double *d_sc = nullptr;
+    RL_HIP(t->pool.alloc(&d_sc, (size_t)d.N));
+    hipLaunchKernelGGL(k_ensemble_eval, dim3((unsigned)std::min<int64_t>(8192, (d.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, t->ens,
+                       t->ctx.MAXN, t->n_kept, (const float *)d.d_X, d.N, t->F, t->p.learning_rate, (float *)nullptr, d_sc);
+    int rc = launch_ndcg(t, d, d_sc, d.d_ndcg);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_double_mean, dim3(1), dim3(64), 0, s, (const double *)d.d_ndcg, d.Q, t->d_mean);
+    RL_HIP(hipGetLastError());
+    RL_HIP(hipStreamSynchronize(s));
+    RL_HIP(hipMemcpy(out, t->d_mean, sizeof(double), hipMemcpyDeviceToHost));
+    t->pool.release(d_sc);
+    return RL_OK;
+}
+
+int rl_finish(rl_trainer *t, double *train_score, double *valid_score)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    if (!t->inited) return fail(RL_ERR_STATE, "rl_init has not been called");
+    RL_HIP(hipSetDevice(t->p.device));
+    int rc = sync_rounds(t);
+    if (rc) return rc;
+    if ((int64_t)t->n_kept > (int64_t)t->best_round + 1) t->n_kept = t->best_round + 1;      // LambdaMART.java:254-256
+    double ts = 0, vs = 0;
+    rc = final_score(t, t->tr, &ts);                                                          // :259
+    if (rc) return rc;
+    if (train_score) *train_score = ts;
+    if (t->has_valid) {
+        rc = final_score(t, t->va, &vs);                                                      // :263
+        if (rc) return rc;
+        t->best_score = vs;
+        if (valid_score) *valid_score = vs;
+    }
+    t->finished = true;
+    return RL_OK;
+}
+
+int rl_num_trees(const rl_trainer *t, int32_t *n)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    if (n) *n = t->n_kept;
+    return RL_OK;
+}
+
+int rl_get_tree(const rl_trainer *t, int32_t i, rl_tree *out)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    if (!out) return fail(RL_ERR_INVALID, "null tree");
+    if (i < 0 || i >= t->synced_rounds) return fail(RL_ERR_INVALID, "tree index out of range (did you rl_sync?)");
+    RL_HIP(hipSetDevice(t->p.device));
+    HostTree h;
+    int rc = fetch_tree(t, i, h);
+    if (rc) return rc;
+    out->n_nodes = h.n_nodes;
+    if (out->cap < h.n_nodes) return fail(RL_ERR_INVALID, "rl_tree.cap too small");
+    for (int j = 0; j < h.n_nodes; j++) {
+        out->feature[j] = h.feature[j]; out->threshold[j] = h.threshold[j]; out->left[j] = h.left[j]; out->right[j] = h.right[j];
+        out->output[j] = h.output[j];
+        if (out->deviance) out->deviance[j] = h.deviance[j];
+        if (out->count) out->count[j] = h.count[j];
+    }
+    return RL_OK;
+}
+
+int rl_get_round_metrics(const rl_trainer *t, int32_t round, float *train_metric, float *valid_metric)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    if (round < 0 || round >= t->synced_rounds) return fail(RL_ERR_INVALID, "round out of range (did you rl_sync?)");
+    if (train_metric) *train_metric = t->h_metrics[2 * (size_t)round];
+    if (valid_metric && t->has_valid) *valid_metric = t->h_metrics[2 * (size_t)round + 1];
+    return RL_OK;
+}
+
+int rl_best_validation(const rl_trainer *t, int32_t *best_round, double *best_score)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    if (best_round) *best_round = t->best_round;
+    if (best_score) *best_score = t->best_score;
+    return RL_OK;
+}
+
+int rl_predict(rl_trainer *t, const float *X, int64_t n_docs, float *out)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    if (!t->inited) return fail(RL_ERR_STATE, "rl_init has not been called");
+    if (!X || !out || n_docs < 0) return fail(RL_ERR_INVALID, "bad argument");
+    if (n_docs == 0) return RL_OK;
+    RL_HIP(hipSetDevice(t->p.device));
+    int rc = sync_rounds(t);
+    if (rc) return rc;
+    float *dX = nullptr, *dO = nullptr;
+    RL_HIP(hipMalloc((void **)&dX, (size_t)n_docs * t->F * sizeof(float)));
+    RL_HIP(hipMalloc((void **)&dO, (size_t)n_docs * sizeof(float)));
+    RL_HIP(hipMemcpy(dX, X, (size_t)n_docs * t->F * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_ensemble_eval, dim3((unsigned)std::min<int64_t>(8192, (n_docs + kThreads - 1) / kThreads)), dim3(kThreads), 0, t->stream,
+                       t->ens, t->ctx.MAXN, t->n_kept, (const float *)dX, n_docs, t->F, t->p.learning_rate, dO, (double *)nullptr);
+    RL_HIP(hipGetLastError());
+    RL_HIP(hipStreamSynchronize(t->stream));
+    RL_HIP(hipMemcpy(out, dO, (size_t)n_docs * sizeof(float), hipMemcpyDeviceToHost));
+    (void)hipFree(dX); (void)hipFree(dO);
+    return RL_OK;
+}
+
+int rl_model_to_text(const rl_trainer *t, char *buf, int64_t cap, int64_t *needed)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    if (!t->inited) return fail(RL_ERR_STATE, "rl_init has not been called");
+    RL_HIP(hipSetDevice(t->p.device));
+    if (t->synced_rounds < t->n_kept) return fail(RL_ERR_STATE, "rounds still in flight: call rl_sync first");
+    std::vector<HostTree> trees((size_t)t->n_kept);
+    for (int i = 0; i < t->n_kept; i++) { int rc = fetch_tree(t, i, trees[i]); if (rc) return rc; }
+    ModelHeader h{t->p.n_trees, t->p.n_leaves, t->p.n_threshold, t->p.learning_rate, t->p.early_stop_rounds};
+    const std::string s = model_to_text(h, trees);                // LambdaMART.model()  LambdaMART.java:290-301
+    if (needed) *needed = (int64_t)s.size() + 1;
+    if (buf && cap >= (int64_t)s.size() + 1) memcpy(buf, s.c_str(), s.size() + 1);
+    return RL_OK;
+}
+
+// ---- multi-GPU: filled in by rl_dist.hip when built with RCCL -------------------------------------
+int rl_dist_unique_id(void *id_out) { (void)id_out; return fail(RL_ERR_UNSUPPORTED, "multi-GPU path not built yet"); }
+int rl_dist_init(rl_trainer *t, const void *id, int32_t rank, int32_t n_ranks)
+{
+    (void)t; (void)id; (void)rank; (void)n_ranks;
+    return fail(RL_ERR_UNSUPPORTED, "multi-GPU path not built yet");
+}
+
+// ---- introspection -------------------------------------------------------------------------------
+int rl_bin_stride(const rl_trainer *t, int32_t *stride)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    if (!t->inited) return fail(RL_ERR_STATE, "rl_init has not been called");
+    if (stride) *stride = t->ctx.TS;
+    return RL_OK;
+}
+
+int rl_quant_exponent(const rl_trainer *t, int32_t *e)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    if (!t->inited) return fail(RL_ERR_STATE, "rl_init has not been called");
+    TreeState st;
+    RL_HIP(hipMemcpy(&st, t->ctx.st, sizeof(st), hipMemcpyDeviceToHost));
+    if (e) *e = st.E;
+    return RL_OK;
+}
+
+int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    if (!t->inited) return fail(RL_ERR_STATE, "rl_init has not been called");
+    RL_HIP(hipSetDevice(t->p.device));
+    RL_HIP(hipStreamSynchronize(t->stream));
+    const Ctx &c = t->ctx;
+    const void *src = nullptr; size_t bytes = 0;
+    switch (which) {
+    case RL_ARR_LAMBDA: src = c.lambda; bytes = (size_t)c.N * 8; break;
+    case RL_ARR_WEIGHT: src = c.weight; bytes = (size_t)c.N * 8; break;
+    case RL_ARR_SCORE: src = c.scores; bytes = (size_t)c.N * 8; break;
+    case RL_ARR_VALID_SCORE: if (!t->has_valid) return fail(RL_ERR_STATE, "no validation set"); src = t->va.d_scores; bytes = (size_t)t->va.N * 8; break;
+    case RL_ARR_NBINS: src = c.nthr; bytes = (size_t)c.F * 4; break;
+    case RL_ARR_THRESHOLDS: src = c.thr; bytes = (size_t)c.F * c.TS * 4; break;
+    case RL_ARR_ROOT_COUNT: src = c.cum_cnt; bytes = (size_t)c.F * c.TS * 4; break;
+    case RL_ARR_QUANT: src = c.q; bytes = (size_t)c.N * 8; break;
+    case RL_ARR_NDCG_PER_QUERY: src = c.ndcg_q; bytes = (size_t)c.Q * 8; break;
+    case RL_ARR_BINS: {
+        bytes = (size_t)c.F * c.N * 2;
+        if ((int64_t)bytes > cap_bytes) return fail(RL_ERR_INVALID, "output buffer too small");
+        RL_HIP(hipMemcpy2D(out, (size_t)c.N * 2, c.bins, (size_t)c.Npad * 2, (size_t)c.N * 2, c.F, hipMemcpyDeviceToHost));
+        return RL_OK;
+    }
+    case RL_ARR_ROOT_SUM:
+    case RL_ARR_ROOT_SUM_FIXED: {
+        const bool fixed = which == RL_ARR_ROOT_SUM_FIXED;
+        bytes = (size_t)c.F * c.TS * (fixed ? 16 : 8);
+        if ((int64_t)bytes > cap_bytes) return fail(RL_ERR_INVALID, "output buffer too small");
+        void *d = nullptr;
+        RL_HIP(hipMalloc(&d, bytes));
+        RL_HIP(hipMemset(d, 0, bytes));
+        hipLaunchKernelGGL(k_debug_root_sum, dim3(c.F), dim3(kThreads), 0, t->stream, c, fixed ? (double *)nullptr : (double *)d,
+                           fixed ? (long long *)d : (long long *)nullptr);
+        RL_HIP(hipStreamSynchronize(t->stream));
+        RL_HIP(hipMemcpy(out, d, bytes, hipMemcpyDeviceToHost));
+        (void)hipFree(d);
+        return RL_OK;
+    }
+    default: return fail(RL_ERR_INVALID, "unknown array id");
+    }
+    if ((int64_t)bytes > cap_bytes) return fail(RL_ERR_INVALID, "output buffer too small");
+    RL_HIP(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
+    return RL_OK;
+}
+
+int rl_get_timing(rl_trainer *t, int32_t kernel, double *total_ms, int64_t *launches, double *alg_bytes)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    if (kernel < 0 || kernel >= RL_KERNEL_COUNT_) return fail(RL_ERR_INVALID, "unknown kernel id");
+    if (total_ms) *total_ms = t->timing[kernel].ms;
+    if (launches) *launches = t->timing[kernel].launches;
+    if (alg_bytes) *alg_bytes = t->timing[kernel].bytes;
+    return RL_OK;
+}
+
+int rl_reset_timing(rl_trainer *t)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    for (auto &s : t->timing) s = TimingSlot();
+    return RL_OK;
+}
+
+
+// ---- scoring-only model (Ensemble loaded from RankLib model text) -----------------------------------
+}  // extern "C"
+
+struct rl_model {
+    int32_t device = 0;
+    std::vector<HostTree> trees;
+    std::vector<int32_t> features;
+    int32_t maxn = 1;
+    bool uniform_weight = true;
+    DevPool pool;
+    EnsTree ens;
+    float *d_w = nullptr;
+};
+
+namespace rl {
+// like k_ensemble_eval but with a weight per tree (Ensemble.weights)
+__global__ __launch_bounds__(kThreads) void k_model_eval(const EnsTree e, const float *w, int MAXN, int nt, const float *X, int64_t n,
+                                                          int stride, float *out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        const float *row = X + (size_t)i * stride;
+        float s = 0.f;
+        for (int t = 0; t < nt; t++) {
+            const size_t o = (size_t)t * MAXN;
+            int nd = 0;
+            while (e.feat_idx[o + nd] != -1) {
+                const int fc = e.feat_idx[o + nd];
+                const float v = (fc < stride) ? row[fc] : 0.f;                 // -missingZero  DenseDataPoint.java:22-25
+                nd = (v <= e.thr[o + nd]) ? e.left[o + nd] : e.right[o + nd];
+            }
+            s = (float)((double)s + (double)e.out[o + nd] * (double)w[t]);     // Ensemble.java:113
+        }
+        out[i] = s;
+    }
+}
+}  // namespace rl
+
+extern "C" {
+
+int rl_model_from_text(const char *text, int32_t device, rl_model **out)
+{
+    if (!text || !out) return fail(RL_ERR_INVALID, "null argument");
+    *out = nullptr;
+    std::unique_ptr<rl_model> m(new rl_model());
+    std::string err;
+    if (!model_from_text(text, m->trees, err)) return fail(RL_ERR_INVALID, "Error in Emsemble(xmlRepresentation): " + err);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RL_ERR_NO_DEVICE, "no HIP device visible: librlhip has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(RL_ERR_INVALID, "device ordinal out of range");
+    m->device = device;
+    RL_HIP(hipSetDevice(device));
+    std::map<int32_t, int> fids;
+    for (auto &t : m->trees) { m->maxn = std::max(m->maxn, t.n_nodes); for (int f : t.feature) if (f != -1) fids[f] = 0; }
+    for (auto &kv : fids) m->features.push_back(kv.first);
+    const size_t nt = m->trees.size(), en = std::max<size_t>(1, nt * m->maxn);
+    std::vector<int32_t> fi(en, -1), le(en, -1), ri(en, -1);
+    std::vector<float> th(en, 0.f), ou(en, 0.f), w(std::max<size_t>(1, nt), 0.f);
+    for (size_t i = 0; i < nt; i++) {
+        const HostTree &t = m->trees[i];
+        w[i] = t.weight;
+        for (int j = 0; j < t.n_nodes; j++) {
+            const size_t o = i * m->maxn + j;
+            fi[o] = t.feature[j]; le[o] = t.left[j]; ri[o] = t.right[j]; th[o] = t.threshold[j]; ou[o] = t.output[j];
+        }
+    }
+    memset(&m->ens, 0, sizeof(m->ens));
+    RL_HIP(m->pool.alloc(&m->ens.feat_idx, en)); RL_HIP(m->pool.alloc(&m->ens.left, en)); RL_HIP(m->pool.alloc(&m->ens.right, en));
+    RL_HIP(m->pool.alloc(&m->ens.thr, en)); RL_HIP(m->pool.alloc(&m->ens.out, en)); RL_HIP(m->pool.alloc(&m->d_w, w.size()));
+    RL_HIP(hipMemcpy(m->ens.feat_idx, fi.data(), en * 4, hipMemcpyHostToDevice));
+    RL_HIP(hipMemcpy(m->ens.left, le.data(), en * 4, hipMemcpyHostToDevice));
+    RL_HIP(hipMemcpy(m->ens.right, ri.data(), en * 4, hipMemcpyHostToDevice));
+    RL_HIP(hipMemcpy(m->ens.thr, th.data(), en * 4, hipMemcpyHostToDevice));
+    RL_HIP(hipMemcpy(m->ens.out, ou.data(), en * 4, hipMemcpyHostToDevice));
+    RL_HIP(hipMemcpy(m->d_w, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    *out = m.release();
+    return RL_OK;
+}
+
+void rl_model_destroy(rl_model *m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    delete m;
+}
+
+int rl_model_num_trees(const rl_model *m, int32_t *n)
+{
+    if (!m) return fail(RL_ERR_INVALID, "null model");
+    if (n) *n = (int32_t)m->trees.size();
+    return RL_OK;
+}
+
+int rl_model_features(const rl_model *m, int32_t *ids, int32_t cap, int32_t *n)
+{
+    if (!m) return fail(RL_ERR_INVALID, "null model");
+    if (n) *n = (int32_t)m->features.size();
+    if (ids) for (int i = 0; i < cap && i < (int)m->features.size(); i++) ids[i] = m->features[i];
+    return RL_OK;
+}
+
+int rl_model_predict(rl_model *m, const float *X, int64_t n_docs, int32_t row_stride, float *out)
+{
+    if (!m) return fail(RL_ERR_INVALID, "null model");
+    if (!X || !out || n_docs < 0 || row_stride < 1) return fail(RL_ERR_INVALID, "bad argument");
+    if (n_docs == 0) return RL_OK;
+    RL_HIP(hipSetDevice(m->device));
+    float *dX = nullptr, *dO = nullptr;
+    RL_HIP(hipMalloc((void **)&dX, (size_t)n_docs * row_stride * sizeof(float)));
+    RL_HIP(hipMalloc((void **)&dO, (size_t)n_docs * sizeof(float)));
+    RL_HIP(hipMemcpy(dX, X, (size_t)n_docs * row_stride * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_model_eval, dim3((unsigned)std::min<int64_t>(8192, (n_docs + kThreads - 1) / kThreads)), dim3(kThreads), 0, 0, m->ens,
+                       (const float *)m->d_w, m->maxn, (int)m->trees.size(), (const float *)dX, n_docs, row_stride, dO);
+    RL_HIP(hipGetLastError());
+    RL_HIP(hipDeviceSynchronize());
+    RL_HIP(hipMemcpy(out, dO, (size_t)n_docs * sizeof(float), hipMemcpyDeviceToHost));
+    (void)hipFree(dX); (void)hipFree(dO);
+    return RL_OK;
+}
+
+}  // extern "C"

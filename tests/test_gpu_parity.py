@@ -1,0 +1,214 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): bit-exact for integer / index work (thresholds, bins, counts, split
+feature + threshold, tree shape); leaf values and scores are compared BIT-EXACT as well (the path emulates
+the Java float chains), which is stricter than the 1e-5 the north star asks for; NDCG within 1e-4 is then
+implied, and asserted with == on the float-accumulated per-round value.
+"""
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+from ranklib_amd import _native as N
+from ranklib_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def make(n_docs, n_feat, kind="ns", seed=0):
+    return synth.make_dataset(n_docs, n_feat, kind, seed_offset=seed)
+
+
+def pair(X, lab, qoff, **kw):
+    args = dict(n_trees=kw.get("n_trees", 5), n_leaves=kw.get("n_leaves", 10))
+    o = O.Oracle(X, lab, qoff, lr=kw.get("lr", 0.1), n_threshold=kw.get("n_threshold", 256), mls=kw.get("mls", 1),
+                 k=kw.get("k", 10), early_stop=kw.get("early_stop", 100), qkey=kw.get("qkey"), **args)
+    g = N.Trainer(learning_rate=kw.get("lr", 0.1), n_threshold=kw.get("n_threshold", 256),
+                  min_leaf_support=kw.get("mls", 1), metric_k=kw.get("k", 10),
+                  early_stop_rounds=kw.get("early_stop", 100), **args)
+    g.set_train(X, lab, qoff, qkey=kw.get("qkey"))
+    return o, g
+
+
+def assert_same_tree(to, tg, ctx=""):
+    a, b = to.trimmed(), tg.trimmed()
+    assert to.n_nodes == tg.n_nodes, ctx
+    assert np.array_equal(a["feature"], b["feature"]), ctx
+    assert np.array_equal(a["threshold"].view(np.uint32), b["threshold"].view(np.uint32)), ctx
+    assert np.array_equal(a["left"], b["left"]) and np.array_equal(a["right"], b["right"]), ctx
+    assert np.array_equal(a["count"], b["count"]), ctx
+    assert np.array_equal(a["output"].view(np.uint32), b["output"].view(np.uint32)), (ctx, a["output"], b["output"])
+
+
+def test_init_thresholds_bins_counts_bit_exact():
+    X, lab, qoff = make(5000, 24, "ns", 1)
+    o, g = pair(X, lab, qoff)
+    o.init(); g.init()
+    nb = g.array("NBINS")
+    thr = g.array("THRESHOLDS")
+    bins = g.array("BINS")
+    cnt = g.array("ROOT_COUNT")
+    for f in range(24):
+        T = o.n_bins(f)
+        assert nb[f] == T
+        assert np.array_equal(thr[f, :T].view(np.uint32), o.thresholds(f).view(np.uint32))
+        assert np.array_equal(bins[f].astype(np.int32), o.bins(f))
+        assert np.array_equal(cnt[f, :T], o.root_count(f))
+    assert nb.max() == 257          # continuous features: the 257th bin (H4)
+
+
+def test_lambdas_weights_bit_exact_round0_and_later():
+    X, lab, qoff = make(6000, 16, "mslr", 2)
+    o, g = pair(X, lab, qoff, n_trees=3, n_leaves=8)
+    o.init(); g.init()
+    for r in range(3):
+        o.round(); g.boost_round()
+        assert np.array_equal(g.array("LAMBDA").view(np.int64), o.lambdas().view(np.int64)), r
+        assert np.array_equal(g.array("WEIGHT").view(np.int64), o.weights().view(np.int64)), r
+        assert np.array_equal(g.array("SCORE").view(np.int64), o.scores().view(np.int64)), r
+
+
+def test_root_histogram_is_exact_fixed_point_sum():
+    X, lab, qoff = make(20000, 12, "ns", 3)
+    o, g = pair(X, lab, qoff, n_trees=1, n_leaves=2)
+    o.init(); g.init()
+    g.boost_round(); o.round()
+    lam = g.array("LAMBDA")
+    E = g.quant_exponent()
+    q = g.array("QUANT")
+    assert np.array_equal(q, np.rint(np.ldexp(lam, E)).astype(np.int64))
+    assert 2 ** 47 <= np.abs(q).max() < 2 ** 49      # 62 - log2(chunk) bits used
+    bins = g.array("BINS")
+    fixed = g.array("ROOT_SUM_FIXED")
+    sums = g.array("ROOT_SUM")
+    nb = g.array("NBINS")
+    for f in range(12):
+        per_bin = [0] * nb[f]
+        for k in range(len(q)):
+            per_bin[bins[f, k]] += int(q[k])
+        run = 0
+        for t in range(nb[f]):
+            run += per_bin[t]
+            hi, lo = int(fixed[f, t, 0]), int(fixed[f, t, 1]) & 0xFFFFFFFFFFFFFFFF
+            assert hi * 2 ** 64 + lo == run, (f, t)      # two's complement: signed hi, unsigned lo
+            assert sums[f, t] == float(Fraction(run, 2 ** E))
+            # and it agrees with the Java-order f64 sum up to rounding noise
+            assert abs(sums[f, t] - o.root_sum(f)[t]) <= 1e-9 * max(1.0, np.abs(lam).sum())
+
+
+@pytest.mark.parametrize("n_docs,n_feat,kind,leaves,mls,rounds,seed", [
+    (3000, 10, "ns", 10, 1, 8, 0),
+    (8000, 136, "ns", 10, 1, 6, 1),       # c0 shape
+    (12000, 20, "mslr", 31, 1, 5, 2),
+    (4000, 8, "ns", 6, 25, 6, 3),
+    (2500, 5, "mslr", 31, 1, 4, 4),
+])
+def test_trees_scores_metrics_bit_exact(n_docs, n_feat, kind, leaves, mls, rounds, seed):
+    X, lab, qoff = make(n_docs, n_feat, kind, seed)
+    o, g = pair(X, lab, qoff, n_trees=rounds, n_leaves=leaves, mls=mls)
+    o.init(); g.init()
+    for r in range(rounds):
+        to, tmo, _, _ = o.round()
+        tg, tmg, _, _ = g.boost_round()
+        assert_same_tree(to, tg, "round %d trace %s" % (r, o.split_trace()))
+        assert np.float32(tmo).view(np.uint32) == np.float32(tmg).view(np.uint32), r
+        assert np.array_equal(g.array("SCORE").view(np.int64), o.scores().view(np.int64)), r
+    so, _ = o.finish()
+    sg, _ = g.finish()
+    assert so == sg
+    assert np.array_equal(g.predict(X[:777]).view(np.uint32), o.predict(X[:777]).view(np.uint32))
+
+
+def test_validation_early_stop_rollback():
+    X, lab, qoff = make(4000, 12, "ns", 5)
+    Xv, labv, qoffv = make(2500, 12, "ns", 6)
+    o, g = pair(X, lab, qoff, n_trees=40, n_leaves=5, early_stop=3)
+    o.set_validation(Xv, labv, qoffv); g.set_validation(Xv, labv, qoffv)
+    o.init(); g.init()
+    for r in range(40):
+        to, tmo, vmo, so = o.round()
+        tg, tmg, vmg, sg = g.boost_round()
+        assert_same_tree(to, tg, "round %d" % r)
+        assert tmo == tmg and vmo == vmg and so == sg, r
+        if so:
+            break
+    assert np.array_equal(g.array("VALID_SCORE").view(np.int64), o.valid_scores().view(np.int64))
+    (ts_o, vs_o), (ts_g, vs_g) = o.finish(), g.finish()
+    assert ts_o == ts_g and vs_o == vs_g
+    assert g.num_trees() == o.trees_kept()
+    assert g.best_validation()[0] == o.best_valid()[0]
+
+
+def test_shared_qid_cache_quirk():
+    X, lab, qoff = make(1500, 6, "ns", 7)
+    Q = len(qoff) - 1
+    qkey = np.arange(Q) // 2          # pairs of consecutive lists share a qid
+    o, g = pair(X, lab, qoff, n_trees=4, n_leaves=6, qkey=qkey)
+    o.init(); g.init()
+    for r in range(4):
+        to, tmo, _, _ = o.round()
+        tg, tmg, _, _ = g.boost_round()
+        assert_same_tree(to, tg, "round %d" % r)
+        assert tmo == tmg
+
+
+def test_long_lists_use_block_kernel_and_tc_variants():
+    rng = np.random.default_rng(9)
+    sizes = [900, 5, 400, 30, 1300, 7]
+    qoff = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    n = int(qoff[-1])
+    X = rng.integers(0, 40, (n, 6)).astype(np.float32) / 4
+    X[:, 1] = rng.random(n).astype(np.float32)
+    lab = np.clip((X[:, 0] + X[:, 1] * 4 + rng.random(n) * 3).astype(np.int32) // 4, 0, 4).astype(np.float32)
+    for tc in (256, 16, -1):
+        Xc = X.copy()
+        if tc == -1:
+            Xc[:, 1] = np.round(Xc[:, 1] * 1000) / 1000      # keep distinct values under the bin limit
+        o, g = pair(Xc, lab, qoff, n_trees=3, n_leaves=7, n_threshold=tc)
+        o.init(); g.init()
+        for r in range(3):
+            to, tmo, _, _ = o.round()
+            tg, tmg, _, _ = g.boost_round()
+            assert_same_tree(to, tg, "tc %d round %d" % (tc, r))
+            assert tmo == tmg
+
+
+def test_model_text_roundtrip_and_scoring():
+    X, lab, qoff = make(3000, 10, "ns", 11)
+    o, g = pair(X, lab, qoff, n_trees=5, n_leaves=6)
+    o.init(); g.init()
+    for _ in range(5):
+        o.round(); g.boost_round()
+    g.finish()
+    text = g.model_text()
+    assert text.startswith("## LambdaMART\n## No. of trees = 5\n## No. of leaves = 6\n"
+                           "## No. of threshold candidates = 256\n## Learning rate = 0.1\n## Stop early = 100\n\n"
+                           "<ensemble>\n\t<tree id=\"1\" weight=\"0.1\">\n\t\t<split>\n")
+    m = N.Model(text)
+    assert m.num_trees() == 5
+    rows = np.zeros((500, 11), np.float32)
+    rows[:, 1:] = X[:500]
+    assert np.array_equal(m.predict_rows(rows).view(np.uint32), o.predict(X[:500]).view(np.uint32))
+
+
+def test_run_twice_is_deterministic_and_async_equals_sync():
+    X, lab, qoff = make(9000, 30, "ns", 12)
+    outs = []
+    for mode in ("sync", "async"):
+        g = N.Trainer(n_trees=6, n_leaves=10)
+        g.set_train(X, lab, qoff)
+        g.init()
+        if mode == "sync":
+            for _ in range(6):
+                g.boost_round(want_tree=False)
+        else:
+            g.boost_rounds_async(6)
+            g.sync()
+        outs.append((g.array("SCORE").copy(), [g.get_tree(i).trimmed() for i in range(6)],
+                     [g.round_metrics(i)[0] for i in range(6)]))
+    assert np.array_equal(outs[0][0].view(np.int64), outs[1][0].view(np.int64))
+    assert outs[0][2] == outs[1][2]
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert np.array_equal(a["feature"], b["feature"]) and np.array_equal(a["output"], b["output"])
