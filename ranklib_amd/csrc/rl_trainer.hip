@@ -452,6 +452,7 @@ int rl_init(rl_trainer *t)
     if (!t->has_train) return fail(RL_ERR_STATE, "no training set");
     if (t->inited) return fail(RL_ERR_STATE, "rl_init called twice");
     RL_HIP(hipSetDevice(t->p.device));
+    RL_HIP(hipDeviceSynchronize());      // uploads of rl_set_* went through the null stream; t->stream is non-blocking
     Ctx &c = t->ctx;
     hipStream_t s = t->stream;
     const int N = (int)t->tr.N, F = t->F;
@@ -732,7 +733,7 @@ int rl_predict(rl_trainer *t, const float *X, int64_t n_docs, float *out)
     float *dX = nullptr, *dO = nullptr;
     RL_HIP(hipMalloc((void **)&dX, (size_t)n_docs * t->F * sizeof(float)));
     RL_HIP(hipMalloc((void **)&dO, (size_t)n_docs * sizeof(float)));
-    RL_HIP(hipMemcpy(dX, X, (size_t)n_docs * t->F * sizeof(float), hipMemcpyHostToDevice));
+    RL_HIP(hipMemcpyAsync(dX, X, (size_t)n_docs * t->F * sizeof(float), hipMemcpyHostToDevice, t->stream));
     hipLaunchKernelGGL(k_ensemble_eval, dim3((unsigned)std::min<int64_t>(8192, (n_docs + kThreads - 1) / kThreads)), dim3(kThreads), 0, t->stream,
                        t->ens, t->ctx.MAXN, t->n_kept, (const float *)dX, n_docs, t->F, t->p.learning_rate, dO, (double *)nullptr);
     RL_HIP(hipGetLastError());
@@ -815,7 +816,7 @@ int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes)
         if ((int64_t)bytes > cap_bytes) return fail(RL_ERR_INVALID, "output buffer too small");
         void *d = nullptr;
         RL_HIP(hipMalloc(&d, bytes));
-        RL_HIP(hipMemset(d, 0, bytes));
+        RL_HIP(hipMemsetAsync(d, 0, bytes, t->stream));      // same stream as the kernel: t->stream is non-blocking
         hipLaunchKernelGGL(k_debug_root_sum, dim3(c.F), dim3(kThreads), 0, t->stream, c, fixed ? (double *)nullptr : (double *)d,
                            fixed ? (long long *)d : (long long *)nullptr);
         RL_HIP(hipStreamSynchronize(t->stream));
