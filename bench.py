@@ -1,0 +1,168 @@
+#!/usr/bin/env python
+"""bench.py -- boosting rounds/sec of the MI355X LambdaMART path (BASELINE.json metric).
+
+A "step" is one boosting round (one iteration of learning/tree/LambdaMART.java:180-251: lambdas,
+root histogram, a 31-leaf tree grown best-first, leaf outputs, score update, train NDCG@10) on synthetic
+MSLR-WEB10K-shaped data that is already resident in HBM when the timed region starts (init() -- binning,
+H2D -- is reported separately, never inside `value`).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...    (queries sharded by rank)
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the root histogram, rl::k_hist<true>):
+algorithmic bytes per launch / HIP-event time of that launch measured live on the library's own stream.
+`cpu_baseline` is the CPU oracle (java-exact restatement with RankLib's thread split) timed on this box's
+host cores on the same data for a bounded number of rounds.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s measured float4 copy
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--shape", default="c1", help="c0 | c1 | c1ns | c2 (ranklib_amd.synth.SHAPES)")
+    ap.add_argument("--cpu-rounds", type=int, default=8, help="rounds timed for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores (RankLib's default -thread)")
+    ap.add_argument("--no-timing", action="store_true", help="do not record HIP events around the dominant kernel")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from ranklib_amd import _native as N
+    from ranklib_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n_docs, n_feat, kind, n_trees, n_leaves = synth.SHAPES[args.shape]
+    t0 = time.time()
+    if world == 1:
+        X, lab, qoff = synth.make_dataset(n_docs, n_feat, kind)
+    else:
+        # weak scaling: every rank holds a full-size shard of its own queries (different seeds per rank)
+        X, lab, qoff = synth.make_dataset(n_docs, n_feat, kind, seed_offset=1000 * rank)
+    t_gen = time.time() - t0
+
+    flags = 0 if args.no_timing else N.RL_FLAG_TIMING
+    total_rounds = args.warmup + args.steps
+    g = N.Trainer(n_trees=max(total_rounds, 1), n_leaves=n_leaves, device=local_rank, flags=flags)
+    t0 = time.time()
+    g.set_train(X, lab, qoff)
+    if world > 1:
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(g.dist_unique_id()), dtype=torch.uint8).cuda()
+        dist.broadcast(uid, 0)
+        g.dist_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+    g.init()
+    t_init = time.time() - t0
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        g.boost_rounds_async(args.warmup)
+        g.sync()
+    g.reset_timing()
+    barrier()
+    t0 = time.perf_counter()
+    g.boost_rounds_async(args.steps)
+    g.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    ndcg_t = float(g.round_metrics(total_rounds - 1)[0])
+    ms_root, n_root, bytes_root = g.timing("HIST_ROOT")
+    ms_node, n_node, _ = g.timing("HIST_NODE")
+    ms_lam, n_lam, _ = g.timing("LAMBDA")
+
+    if rank != 0:
+        return
+    rounds_per_s = args.steps / elapsed
+    out = {
+        "metric": "boosting rounds/sec (LambdaMART -ranker 6, NDCG@10)",
+        "value": rounds_per_s,
+        "unit": "rounds/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1000.0 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int64 fixed-point histograms + f64 lambdas/scores (f32 leaf chains as in the Java)",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE.json configs[1]: MSLR-WEB10K-shape %s: %d docs x %d features, %d queries (%s docs/query), "
+                        "%d leaves, lr 0.1, -tc 256, -mls 1, NDCG@10; per GPU" %
+                        (args.shape, n_docs, n_feat, len(qoff) - 1, "~120 log-normal" if kind == "mslr" else "5..15", n_leaves),
+            "docs_per_gpu": n_docs, "features": n_feat, "queries_per_gpu": int(len(qoff) - 1), "leaves": n_leaves,
+            "ndcg10_train_after_%d_rounds" % total_rounds: ndcg_t,
+            "init_seconds": round(t_init, 3), "datagen_seconds": round(t_gen, 3),
+        },
+    }
+    if n_root > 0:
+        per_launch_ms = ms_root / n_root
+        alg_bytes = bytes_root / n_root
+        achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
+        out["roofline"] = {
+            "kernel": "rl::k_hist<true> (root histogram, FeatureHistogram.update)",
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": per_launch_ms, "launches": int(n_root),
+            "note": "algorithmic bytes = N*(F*2 B bin ids + 8 B fixed-point lambda); HIP events on the library stream",
+        }
+        out["kernel_ms_per_round"] = {"hist_root": ms_root / args.steps, "hist_node": ms_node / args.steps,
+                                      "lambda": ms_lam / args.steps}
+
+    if args.cpu_rounds > 0:
+        import oracle_ffi as O
+        threads = args.cpu_threads or (os.cpu_count() or 1)
+        o = O.Oracle(X, lab, qoff, n_trees=args.cpu_rounds, n_leaves=n_leaves, n_threads=threads)
+        tc = time.perf_counter()
+        o.init()
+        t_cpu_init = time.perf_counter() - tc
+        tc = time.perf_counter()
+        for _ in range(args.cpu_rounds):
+            o.round()
+        t_cpu = time.perf_counter() - tc
+        out["cpu_baseline"] = {
+            "value": args.cpu_rounds / t_cpu, "unit": "rounds/s", "cores": threads, "kind": "port",
+            "sample": "same data set, %d boosting rounds of the java-exact C oracle with RankLib's MyThreadPool work split "
+                      "(init %.1f s not counted)" % (args.cpu_rounds, t_cpu_init),
+        }
+        out["speedup_vs_cpu_baseline"] = rounds_per_s / (args.cpu_rounds / t_cpu)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
