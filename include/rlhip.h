@@ -59,7 +59,9 @@ enum { RL_METRIC_NDCG = 0 };            /* metric/NDCGScorer.java (others: SURVE
 enum {                                  /* rl_params.flags */
     RL_FLAG_FAST_LEAF = 1,              /* leaf sums as exact-f64 tree sums instead of emulating the Java float
                                            running sums (learning/tree/LambdaMART.java:401-408).  NOT parity. */
-    RL_FLAG_TIMING = 2                  /* record HIP events around the dominant kernels (rl_get_timing) */
+    RL_FLAG_TIMING = 2,                 /* record HIP events around the dominant kernels (rl_get_timing) */
+    RL_FLAG_SERIAL_CHAIN = 4            /* evaluate the float running sums with the literal serial kernel instead of
+                                           the exact parallel scheme (same results; for cross-checks) */
 };
 
 typedef struct rl_trainer rl_trainer;   /* opaque */
@@ -174,7 +176,9 @@ enum {
     RL_ARR_ROOT_SUM = 9,     /* double[n_features*stride]   cumulative root sums of the last round */
     RL_ARR_QUANT = 10,       /* int64[n_docs]               fixed-point lambdas of the last round */
     RL_ARR_ROOT_SUM_FIXED = 11, /* int64[2*n_features*stride] (hi,lo) 128-bit cumulative fixed-point sums */
-    RL_ARR_NDCG_PER_QUERY = 12  /* double[n_queries] of the last round */
+    RL_ARR_NDCG_PER_QUERY = 12, /* double[n_queries] of the last round */
+    RL_ARR_CHAIN_STATS = 13     /* int32[4]: leaf float chains evaluated, of which needed the serial fallback;
+                                   metric chains evaluated, of which needed the serial fallback */
 };
 int rl_bin_stride(const rl_trainer *t, int32_t *stride);
 int rl_quant_exponent(const rl_trainer *t, int32_t *e);   /* q = rint(lambda * 2^e) in the last round */

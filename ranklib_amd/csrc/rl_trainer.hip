@@ -16,6 +16,7 @@
 #include "rl_internal.h"
 #include "rl_device.h"
 #include "rl_kernels_init.inc"
+#include "rl_chain.inc"
 #include "rl_kernels_round.inc"
 #include "rl_model.h"
 
@@ -75,6 +76,8 @@ struct rl_trainer {
     std::vector<float> h_metrics;            // [round][2]
     std::vector<HostTree> trees;             // host copies (pre-order), fetched lazily
     float *d_final_f = nullptr; double *d_final_d = nullptr, *d_mean = nullptr;
+    ChainBufs leaf_chain, metric_chain;      // exact parallel float chains (rl_chain.inc)
+    int32_t *d_seg_buf = nullptr;
     float *d_vmetric = nullptr;
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending[RL_KERNEL_COUNT_];
@@ -191,6 +194,58 @@ static void collect_timing(rl_trainer *t)
     }
 }
 
+
+// ---- exact parallel float chains (rl_chain.inc) ------------------------------------------------------
+static int alloc_chain(rl_trainer *t, ChainBufs &b, int maxseg, int A, int64_t n)
+{
+    memset(&b, 0, sizeof(b));
+    b.maxseg = maxseg; b.A = A;
+    b.cap_tiles = n / kChainTile + maxseg + 2;
+    b.cap_chunks = b.cap_tiles + maxseg + 2;
+    b.cap_n = std::max<int64_t>(n, b.cap_chunks);
+    if (b.cap_chunks / kChainGroup + 2 > (160 * 1024) / (kChainW * 4))
+        return fail(RL_ERR_UNSUPPORTED, "data set too large for the float-chain stitch kernel");
+    RL_HIP(t->pool.alloc(&b.plan, (size_t)1));
+    RL_HIP(t->pool.alloc(&b.seg_start, (size_t)maxseg + 2)); RL_HIP(t->pool.alloc(&b.seg_tile0, (size_t)maxseg + 2));
+    RL_HIP(t->pool.alloc(&b.xs, (size_t)A * b.cap_n)); RL_HIP(t->pool.alloc(&b.pre, (size_t)A * b.cap_n));
+    RL_HIP(t->pool.alloc(&b.tile_tot, (size_t)A * b.cap_tiles)); RL_HIP(t->pool.alloc(&b.tile_base, (size_t)A * b.cap_tiles));
+    RL_HIP(t->pool.alloc(&b.bnd, (size_t)A * b.cap_tiles));
+    RL_HIP(t->pool.alloc(&b.cbase, (size_t)A * b.cap_chunks)); RL_HIP(t->pool.alloc(&b.drift, (size_t)A * b.cap_chunks));
+    RL_HIP(t->pool.alloc(&b.gkey, (size_t)A * b.cap_chunks)); RL_HIP(t->pool.alloc(&b.R, (size_t)A * b.cap_chunks * kChainW));
+    RL_HIP(t->pool.alloc(&b.result, (size_t)A * maxseg)); RL_HIP(t->pool.alloc(&b.miss, (size_t)A * maxseg));
+    RL_HIP(t->pool.alloc(&b.stats, (size_t)2));
+    RL_HIP(hipMemset(b.stats, 0, 2 * sizeof(int32_t)));
+    RL_HIP(hipMemset(b.plan, 0, sizeof(ChainPlan)));
+    return RL_OK;
+}
+
+// the plan must already be on the device (k_leaf_table / k_plan_single); grids are sized by capacity
+static void enqueue_chain(rl_trainer *t, const ChainBufs &b, const ChainSource &src)
+{
+    hipStream_t s = t->stream;
+    const unsigned tb = (unsigned)((b.cap_tiles + 3) / 4);
+    hipLaunchKernelGGL(k_chain_prefix, dim3(tb, b.A), dim3(kThreads), 0, s, b, src);
+    hipLaunchKernelGGL(k_chain_scan_tiles, dim3(b.A), dim3(kThreads), 0, s, b);
+    hipLaunchKernelGGL(k_chain_bounds, dim3(tb, b.A), dim3(kThreads), 0, s, b);
+    hipLaunchKernelGGL(k_chain_pass1, dim3((unsigned)((b.cap_chunks + kThreads - 1) / kThreads), b.A), dim3(kThreads), 0, s, b);
+    hipLaunchKernelGGL(k_chain_guess, dim3(b.A), dim3(kThreads), 0, s, b);
+    hipLaunchKernelGGL(k_chain_tables, dim3((unsigned)((b.cap_chunks * kChainW + kThreads - 1) / kThreads), b.A), dim3(kThreads), 0, s, b);
+    const size_t lds = (size_t)(b.cap_chunks / kChainGroup + 2) * kChainW * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_chain_stitch, dim3(b.maxseg, b.A), dim3(kThreads), lds, s, b);
+    hipLaunchKernelGGL(k_chain_fallback, dim3(b.maxseg, b.A), dim3(64), 0, s, b);
+}
+
+// float s = 0; for (q) s += ndcg_q; s / Q   -- serial for short lists, exact parallel chain otherwise
+static void enqueue_metric_mean(rl_trainer *t, const double *ndcg_q, int Q, float *out)
+{
+    hipStream_t s = t->stream;
+    if (Q <= 4096 || (t->p.flags & RL_FLAG_SERIAL_CHAIN)) { hipLaunchKernelGGL(k_float_mean, dim3(1), dim3(64), 0, s, ndcg_q, Q, out); return; }
+    hipLaunchKernelGGL(k_plan_single, dim3(1), dim3(64), 0, s, t->metric_chain, Q);
+    ChainSource src{ndcg_q, nullptr, nullptr, nullptr, nullptr};
+    enqueue_chain(t, t->metric_chain, src);
+    hipLaunchKernelGGL(k_metric_finish, dim3(1), dim3(64), 0, s, t->metric_chain, Q, out);
+}
+
 // ---- per-query kernels on a data set -------------------------------------------------------------
 static int launch_ndcg(rl_trainer *t, DataSet &d, const double *scores, double *out)
 {
@@ -240,21 +295,27 @@ static int enqueue_round(rl_trainer *t)
         hipLaunchKernelGGL(k_hist_finish<false>, dim3(c.F), dim3(kThreads), fin_lds, s, c);
         hipLaunchKernelGGL(k_select, dim3(1), dim3(64), 0, s, c, 0);
     }
-    hipLaunchKernelGGL(k_leaf_table, dim3(1), dim3(64), 0, s, c);
-    hipLaunchKernelGGL(k_leaf_chain, dim3(c.L), dim3(64), 0, s, c);
+    hipLaunchKernelGGL(k_leaf_table, dim3(1), dim3(64), 0, s, c, t->leaf_chain, t->d_seg_buf);
+    if (t->p.flags & RL_FLAG_SERIAL_CHAIN) {
+        hipLaunchKernelGGL(k_leaf_chain, dim3(c.L), dim3(64), 0, s, c);
+    } else {   // K7: the two Java float running sums of every leaf, exactly, in parallel (rl_chain.inc)
+        ChainSource src{c.lambda, c.weight, c.idx[0], c.idx[1], t->d_seg_buf};
+        enqueue_chain(t, t->leaf_chain, src);
+        hipLaunchKernelGGL(k_leaf_output, dim3((c.L + kThreads - 1) / kThreads), dim3(kThreads), 0, s, c, t->leaf_chain);
+    }
     hipLaunchKernelGGL(k_score_update, dim3(std::min(4096, (c.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, c);
     hipLaunchKernelGGL(k_export_tree, dim3(1), dim3(kThreads), 0, s, c, t->ens, m);
     RL_HIP(hipGetLastError());
     // per-round training metric (LambdaMART.java:216)
     int rc = launch_ndcg(t, t->tr, c.scores, t->tr.d_ndcg);
     if (rc != RL_OK) return rc;
-    hipLaunchKernelGGL(k_float_mean, dim3(1), dim3(64), 0, s, (const double *)t->tr.d_ndcg, t->tr.Q, c.round_metric + 2 * (size_t)m);
+    enqueue_metric_mean(t, t->tr.d_ndcg, t->tr.Q, c.round_metric + 2 * (size_t)m);
     if (t->has_valid) {   // :228-237
         hipLaunchKernelGGL(k_valid_update, dim3(std::min<int64_t>(4096, (t->va.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
                            t->ens, c.MAXN, m, (const float *)t->va.d_X, (int)t->va.N, c.F, c.lr, t->va.d_scores);
         rc = launch_ndcg(t, t->va, t->va.d_scores, t->va.d_ndcg);
         if (rc != RL_OK) return rc;
-        hipLaunchKernelGGL(k_float_mean, dim3(1), dim3(64), 0, s, (const double *)t->va.d_ndcg, t->va.Q, c.round_metric + 2 * (size_t)m + 1);
+        enqueue_metric_mean(t, t->va.d_ndcg, t->va.Q, c.round_metric + 2 * (size_t)m + 1);
     }
     RL_HIP(hipGetLastError());
     t->round = m + 1;
@@ -394,6 +455,7 @@ int rl_create(const rl_params *p, rl_trainer **out)
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
     RL_HIP(hipFuncSetAttribute((const void *)k_ndcg_block, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaBlockCap * 12));
+    RL_HIP(hipFuncSetAttribute((const void *)k_chain_stitch, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     *out = t.release();
     return RL_OK;
 }
@@ -590,6 +652,13 @@ int rl_init(rl_trainer *t)
     RL_HIP(t->pool.alloc(&t->ens.n_nodes, (size_t)t->p.n_trees));
     RL_HIP(hipMemset(t->ens.n_nodes, 0, t->p.n_trees * sizeof(int32_t)));
     RL_HIP(t->pool.alloc(&t->d_mean, (size_t)2));
+    {
+        int rc = alloc_chain(t, t->leaf_chain, c.MAXN + 1, 2, N);
+        if (rc) return rc;
+        rc = alloc_chain(t, t->metric_chain, 1, 1, std::max(t->tr.Q, t->has_valid ? t->va.Q : 0));
+        if (rc) return rc;
+        RL_HIP(t->pool.alloc(&t->d_seg_buf, (size_t)c.MAXN + 2));
+    }
     RL_HIP(hipDeviceSynchronize());
     t->inited = true;
     return RL_OK;
@@ -803,6 +872,12 @@ int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes)
     case RL_ARR_ROOT_COUNT: src = c.cum_cnt; bytes = (size_t)c.F * c.TS * 4; break;
     case RL_ARR_QUANT: src = c.q; bytes = (size_t)c.N * 8; break;
     case RL_ARR_NDCG_PER_QUERY: src = c.ndcg_q; bytes = (size_t)c.Q * 8; break;
+    case RL_ARR_CHAIN_STATS: {
+        if (cap_bytes < 16) return fail(RL_ERR_INVALID, "output buffer too small");
+        RL_HIP(hipMemcpy(out, t->leaf_chain.stats, 8, hipMemcpyDeviceToHost));
+        RL_HIP(hipMemcpy((char *)out + 8, t->metric_chain.stats, 8, hipMemcpyDeviceToHost));
+        return RL_OK;
+    }
     case RL_ARR_BINS: {
         bytes = (size_t)c.F * c.N * 2;
         if ((int64_t)bytes > cap_bytes) return fail(RL_ERR_INVALID, "output buffer too small");

@@ -245,3 +245,32 @@ def test_run_twice_is_deterministic_and_async_equals_sync():
     assert outs[0][2] == outs[1][2]
     for a, b in zip(outs[0][1], outs[1][1]):
         assert np.array_equal(a["feature"], b["feature"]) and np.array_equal(a["output"], b["output"])
+
+
+def test_exact_parallel_float_chain_equals_serial_chain_and_oracle():
+    """rl_chain.inc: speculative-window evaluation of the Java float running sums must equal the literal serial
+    kernel (RL_FLAG_SERIAL_CHAIN) and the oracle bit for bit, including the metric chain over > 4096 queries."""
+    X, lab, qoff = make(60000, 12, "ns", 21)          # ~6000 queries -> parallel metric chain
+    res = []
+    for flags in (0, N.RL_FLAG_SERIAL_CHAIN):
+        g = N.Trainer(n_trees=6, n_leaves=12, flags=flags)
+        g.set_train(X, lab, qoff)
+        g.init()
+        trees, mets = [], []
+        for _ in range(6):
+            t, tm, _, _ = g.boost_round()
+            trees.append(t.trimmed()); mets.append(tm)
+        res.append((trees, mets, g.array("SCORE"), g.array("CHAIN_STATS")))
+    (ta, ma, sa, st_a), (tb, mb, sb, st_b) = res
+    assert st_a[0] > 0 and st_a[2] == 6 and st_b[0] == 0
+    assert ma == mb and np.array_equal(sa.view(np.int64), sb.view(np.int64))
+    for a, b in zip(ta, tb):
+        assert np.array_equal(a["output"].view(np.uint32), b["output"].view(np.uint32))
+        assert np.array_equal(a["feature"], b["feature"])
+    o = O.Oracle(X, lab, qoff, n_trees=6, n_leaves=12)
+    o.init()
+    for r in range(6):
+        _, tmo, _, _ = o.round()
+        assert tmo == ma[r]
+    assert np.array_equal(o.scores().view(np.int64), sa.view(np.int64))
+    print("chain stats (leaf segs, leaf fallbacks, metric segs, metric fallbacks):", st_a)
