@@ -14,6 +14,8 @@ constexpr int kThreads = 256;        // 4 wavefronts of 64
 constexpr int kWave = 64;
 constexpr int kLog2Chunk = 13;       // docs accumulated into one LDS histogram copy before it is flushed
 constexpr int kChunk = 1 << kLog2Chunk;
+constexpr int kMinChunk = 2048;      // smallest chunk a (small) node is cut into
+constexpr int kHistFG = 8;           // features per histogram block
 constexpr int kPartTile = 2048;      // docs per partition tile (256 threads x 8)
 constexpr int kMaxBins = 4096;       // bin stride limit (thresholds per feature incl. MAX_VALUE)
 constexpr int kHistLdsBytes = 64 * 1024;

@@ -277,10 +277,12 @@ static int enqueue_round(rl_trainer *t)
     hipLaunchKernelGGL(k_quantize, dim3(std::min(2048, (c.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, c);
     const size_t hist_lds = (size_t)c.FG * c.TS * 12;
     const size_t fin_lds = (size_t)c.TS * 20;
-    const int rootChunks = (c.N + kChunk - 1) / kChunk;
+    const int rootCs = std::min(kChunk, std::max(kMinChunk, (((c.N + 63) / 64 + 255) & ~255)));   // == chunk_docs(N)
+    const int rootChunks = (c.N + rootCs - 1) / rootCs;
     {   // K2 root histogram
         ScopedTiming tm(t, RL_KERNEL_HIST_ROOT, (double)c.N * ((double)c.F * 2.0 + 8.0));
-        hipLaunchKernelGGL(k_hist<true>, dim3(c.numFG, rootChunks), dim3(kThreads), hist_lds, s, c);
+        if (c.FG == kHistFG) hipLaunchKernelGGL((k_hist<true, kHistFG>), dim3(c.numFG, rootChunks), dim3(kThreads), hist_lds, s, c);
+        else hipLaunchKernelGGL((k_hist<true, 1>), dim3(c.numFG, rootChunks), dim3(kThreads), hist_lds, s, c);
     }
     hipLaunchKernelGGL(k_hist_finish<true>, dim3(c.F), dim3(kThreads), fin_lds, s, c);
     hipLaunchKernelGGL(k_select, dim3(1), dim3(64), 0, s, c, 1);
@@ -290,7 +292,8 @@ static int enqueue_round(rl_trainer *t)
         hipLaunchKernelGGL(k_part_scatter, dim3(c.nTiles), dim3(kThreads), 0, s, c);
         {
             ScopedTiming tm(t, RL_KERNEL_HIST_NODE, 0.0);
-            hipLaunchKernelGGL(k_hist<false>, dim3(c.numFG, c.maxChunks), dim3(kThreads), hist_lds, s, c);
+            if (c.FG == kHistFG) hipLaunchKernelGGL((k_hist<false, kHistFG>), dim3(c.numFG, c.maxChunks), dim3(kThreads), hist_lds, s, c);
+            else hipLaunchKernelGGL((k_hist<false, 1>), dim3(c.numFG, c.maxChunks), dim3(kThreads), hist_lds, s, c);
         }
         hipLaunchKernelGGL(k_hist_finish<false>, dim3(c.F), dim3(kThreads), fin_lds, s, c);
         hipLaunchKernelGGL(k_select, dim3(1), dim3(64), 0, s, c, 0);
@@ -450,8 +453,10 @@ int rl_create(const rl_params *p, rl_trainer **out)
     RL_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
     RL_HIP(hipFuncSetAttribute((const void *)k_lambda_block, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaBlockCap * 32));
     RL_HIP(hipFuncSetAttribute((const void *)k_lambda_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kLambdaWaveCap * 32));
-    RL_HIP(hipFuncSetAttribute((const void *)k_hist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
-    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, kHistFG>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, kHistFG>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
     RL_HIP(hipFuncSetAttribute((const void *)k_ndcg_block, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaBlockCap * 12));
@@ -569,15 +574,15 @@ int rl_init(rl_trainer *t)
     RL_HIP(hipMemcpy2DAsync(d_thr, TS * sizeof(float), thr0, TS0 * sizeof(float), TS * sizeof(float), F, hipMemcpyDeviceToDevice, s));
     c.thr = d_thr; c.nthr = d_nthr;
     if ((size_t)TS * 12 > (size_t)kHistLdsBytes) return fail(RL_ERR_UNSUPPORTED, "too many threshold candidates for the LDS histogram");
-    c.FG = std::max(1, std::min(F, (int)(kHistLdsBytes / ((size_t)TS * 12))));
-    if (c.FG > 16) c.FG = 16;
+    // features per histogram block: kHistFG when the LDS budget allows, else 1 (very wide threshold tables)
+    c.FG = ((size_t)kHistFG * TS * 12 <= (size_t)kHistLdsBytes) ? kHistFG : 1;
     c.numFG = (F + c.FG - 1) / c.FG;
 
     uint16_t *d_bins = nullptr;
     RL_HIP(t->pool.alloc(&d_bins, (size_t)F * Npad));
     RL_HIP(hipMemsetAsync(d_bins, 0, (size_t)F * Npad * sizeof(uint16_t), s));
     c.bins = d_bins;
-    c.maxChunks = (N + kChunk - 1) / kChunk;
+    c.maxChunks = std::max((N + kChunk - 1) / kChunk, 64) + 1;      // see chunk_docs()
     c.nTiles = (N + kPartTile - 1) / kPartTile;
     RL_HIP(t->pool.alloc(&c.cum_hi, (size_t)c.MAXN * F * TS));
     RL_HIP(t->pool.alloc(&c.cum_lo, (size_t)c.MAXN * F * TS));
