@@ -48,7 +48,9 @@ struct DataSet {
     float *d_X = nullptr;          // row-major rows [N][F]
     float *d_labels = nullptr; int32_t *d_qoff = nullptr; double *d_ideal0 = nullptr, *d_ideal1 = nullptr;
     double *d_scores = nullptr, *d_ndcg = nullptr;
+    double *d_ss = nullptr; float *d_sl = nullptr; int32_t *d_srel = nullptr, *d_sidx = nullptr, *d_docq = nullptr;   // ranked order (training set only)
     int32_t *d_qsmall = nullptr, *d_qbig = nullptr; int32_t n_small = 0, n_big = 0; bool all_small = false;
+    int32_t *d_q128 = nullptr, *d_qlong = nullptr; int32_t n_q128 = 0, n_qlong = 0;   // split at kLambdaFusedSmall
     int32_t maxq = 0;
 };
 
@@ -78,6 +80,7 @@ struct rl_trainer {
     float *d_final_f = nullptr; double *d_final_d = nullptr, *d_mean = nullptr;
     ChainBufs leaf_chain, metric_chain;      // exact parallel float chains (rl_chain.inc)
     int32_t *d_seg_buf = nullptr;
+    double2 *d_T = nullptr;                  // pair terms of the lambda computation [N][k]
     float *d_vmetric = nullptr;
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending[RL_KERNEL_COUNT_];
@@ -158,6 +161,12 @@ static int upload_query_side(rl_trainer *t, DataSet &d, const std::vector<double
     RL_HIP(t->pool.alloc(&d.d_qbig, big.size()));
     if (!small.empty()) RL_HIP(hipMemcpy(d.d_qsmall, small.data(), small.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (!big.empty()) RL_HIP(hipMemcpy(d.d_qbig, big.data(), big.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    std::vector<int32_t> q128, qlong;
+    for (int32_t q = 0; q < d.Q; q++) ((d.qoff[q + 1] - d.qoff[q]) <= kLambdaFusedSmall ? q128 : qlong).push_back(q);
+    d.n_q128 = (int32_t)q128.size(); d.n_qlong = (int32_t)qlong.size();
+    RL_HIP(t->pool.alloc(&d.d_q128, q128.size())); RL_HIP(t->pool.alloc(&d.d_qlong, qlong.size()));
+    if (!q128.empty()) RL_HIP(hipMemcpy(d.d_q128, q128.data(), q128.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (!qlong.empty()) RL_HIP(hipMemcpy(d.d_qlong, qlong.data(), qlong.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     return RL_OK;
 }
 
@@ -247,14 +256,18 @@ static void enqueue_metric_mean(rl_trainer *t, const double *ndcg_q, int Q, floa
 }
 
 // ---- per-query kernels on a data set -------------------------------------------------------------
-static int launch_ndcg(rl_trainer *t, DataSet &d, const double *scores, double *out)
+// rank every query by `scores` (stable, descending) and leave NDCG@k per query in `out`; with `ranked` the
+// ranked-order arrays of the data set are refreshed too (they feed the next round's lambdas)
+static int launch_rank(rl_trainer *t, DataSet &d, const double *scores, double *out, bool ranked)
 {
-    NdcgArgs a{scores, d.d_labels, d.d_qoff, d.d_ideal1, t->ctx.disc, out, d.Q, t->p.metric_k};
+    RankArgs a{scores, d.d_labels, d.d_qoff, d.d_ideal1, t->ctx.disc,
+               ranked ? d.d_ss : nullptr, ranked ? d.d_sl : nullptr, ranked ? d.d_srel : nullptr, ranked ? d.d_sidx : nullptr,
+               out, t->p.metric_k};
     if (d.n_small > 0)
-        hipLaunchKernelGGL(k_ndcg_wave, dim3((d.n_small + 3) / 4), dim3(kThreads), 4 * kLambdaWaveCap * 12, t->stream, a,
+        hipLaunchKernelGGL(k_rank_wave, dim3((d.n_small + 3) / 4), dim3(kThreads), 4 * kLambdaWaveCap * 12, t->stream, a,
                            d.all_small ? (const int *)nullptr : d.d_qsmall, d.n_small);
     if (d.n_big > 0)
-        hipLaunchKernelGGL(k_ndcg_block, dim3(d.n_big), dim3(kThreads), kLambdaBlockCap * 12, t->stream, a, d.d_qbig, d.n_big);
+        hipLaunchKernelGGL(k_rank_block, dim3(d.n_big), dim3(kThreads), kLambdaBlockCap * 12, t->stream, a, d.d_qbig, d.n_big);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
@@ -266,13 +279,21 @@ static int enqueue_round(rl_trainer *t)
     const int m = t->round;
     // round scalars
     RL_HIP(hipMemsetAsync(&c.st->maxabs_bits, 0, sizeof(unsigned long long) + 2 * sizeof(long long), s));
-    {   // K1 lambdas
+    {   // K1 lambdas: pair terms in parallel, then ordered accumulation (ranked order comes from the previous
+        // round's k_rank_* / from rl_init for round 0)
         ScopedTiming tm(t, RL_KERNEL_LAMBDA, (double)c.N * 28.0);
-        if (t->tr.n_small > 0)
-            hipLaunchKernelGGL(k_lambda_wave, dim3((t->tr.n_small + 3) / 4), dim3(kThreads), 4 * kLambdaWaveCap * 32, s, c, m,
-                               t->tr.all_small ? (const int *)nullptr : t->tr.d_qsmall, t->tr.n_small);
-        if (t->tr.n_big > 0)
-            hipLaunchKernelGGL(k_lambda_block, dim3(t->tr.n_big), dim3(kThreads), kLambdaBlockCap * 32, s, c, m, t->tr.d_qbig, t->tr.n_big);
+        LamArgs g{t->tr.d_ss, t->tr.d_sl, t->tr.d_srel, t->tr.d_sidx, c.qoff, t->tr.d_docq, m == 0 ? c.ideal0 : c.ideal1, c.disc,
+                  t->d_T, c.lambda, c.weight, &c.st->maxabs_bits, c.N, c.k, c.k};
+        if (c.k <= kLambdaFusedMaxK) {
+            const size_t l128 = (size_t)c.k * 128 * 16 + (size_t)c.k * 16 + 128 * 4;
+            const size_t l256 = (size_t)c.k * 256 * 16 + (size_t)c.k * 16 + 256 * 4;
+            if (t->tr.n_q128 > 0) hipLaunchKernelGGL(k_lambda_fused<128>, dim3(t->tr.n_q128), dim3(128), l128, s, g, (const int *)t->tr.d_q128, t->tr.n_q128);
+            if (t->tr.n_qlong > 0) hipLaunchKernelGGL(k_lambda_fused<256>, dim3(t->tr.n_qlong), dim3(256), l256, s, g, (const int *)t->tr.d_qlong, t->tr.n_qlong);
+        } else {
+            const unsigned nb = (unsigned)((c.N + kThreads - 1) / kThreads);
+            hipLaunchKernelGGL(k_pair_terms, dim3(nb), dim3(kThreads), 0, s, g);
+            hipLaunchKernelGGL(k_lambda_acc, dim3(nb), dim3(kThreads), 0, s, g);
+        }
     }
     hipLaunchKernelGGL(k_quantize, dim3(std::min(2048, (c.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, c);
     const size_t hist_lds = (size_t)c.FG * c.TS * 12;
@@ -310,13 +331,13 @@ static int enqueue_round(rl_trainer *t)
     hipLaunchKernelGGL(k_export_tree, dim3(1), dim3(kThreads), 0, s, c, t->ens, m);
     RL_HIP(hipGetLastError());
     // per-round training metric (LambdaMART.java:216)
-    int rc = launch_ndcg(t, t->tr, c.scores, t->tr.d_ndcg);
+    int rc = launch_rank(t, t->tr, c.scores, t->tr.d_ndcg, true);      // also the ranking of round m+1's lambdas
     if (rc != RL_OK) return rc;
     enqueue_metric_mean(t, t->tr.d_ndcg, t->tr.Q, c.round_metric + 2 * (size_t)m);
     if (t->has_valid) {   // :228-237
         hipLaunchKernelGGL(k_valid_update, dim3(std::min<int64_t>(4096, (t->va.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
                            t->ens, c.MAXN, m, (const float *)t->va.d_X, (int)t->va.N, c.F, c.lr, t->va.d_scores);
-        rc = launch_ndcg(t, t->va, t->va.d_scores, t->va.d_ndcg);
+        rc = launch_rank(t, t->va, t->va.d_scores, t->va.d_ndcg, false);
         if (rc != RL_OK) return rc;
         enqueue_metric_mean(t, t->va.d_ndcg, t->va.Q, c.round_metric + 2 * (size_t)m + 1);
     }
@@ -451,15 +472,14 @@ int rl_create(const rl_params *p, rl_trainer **out)
     memset(&t->ctx, 0, sizeof(t->ctx));
     memset(&t->ens, 0, sizeof(t->ens));
     RL_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
-    RL_HIP(hipFuncSetAttribute((const void *)k_lambda_block, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaBlockCap * 32));
-    RL_HIP(hipFuncSetAttribute((const void *)k_lambda_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kLambdaWaveCap * 32));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, kHistFG>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, kHistFG>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
-    RL_HIP(hipFuncSetAttribute((const void *)k_ndcg_block, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaBlockCap * 12));
+    RL_HIP(hipFuncSetAttribute((const void *)k_rank_block, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaBlockCap * 12));
+    RL_HIP(hipFuncSetAttribute((const void *)k_lambda_fused<256>, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaFusedMaxK * 256 * 16 + 2048));
     RL_HIP(hipFuncSetAttribute((const void *)k_chain_stitch, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     *out = t.release();
     return RL_OK;
@@ -664,6 +684,19 @@ int rl_init(rl_trainer *t)
         if (rc) return rc;
         RL_HIP(t->pool.alloc(&t->d_seg_buf, (size_t)c.MAXN + 2));
     }
+    {   // ranked-order arrays + pair-term matrix of the lambda kernels
+        DataSet &d = t->tr;
+        RL_HIP(t->pool.alloc(&d.d_ss, (size_t)N)); RL_HIP(t->pool.alloc(&d.d_sl, (size_t)N));
+        RL_HIP(t->pool.alloc(&d.d_srel, (size_t)N)); RL_HIP(t->pool.alloc(&d.d_sidx, (size_t)N)); RL_HIP(t->pool.alloc(&d.d_docq, (size_t)N));
+        std::vector<int32_t> docq((size_t)N);
+        for (int q = 0; q < d.Q; q++) for (int i = d.qoff[q]; i < d.qoff[q + 1]; i++) docq[i] = q;
+        RL_HIP(hipMemcpy(d.d_docq, docq.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice));
+        if ((size_t)N * c.k * sizeof(double2) > ((size_t)16 << 30)) return fail(RL_ERR_UNSUPPORTED, "NDCG@k with this k needs more than 16 GiB of pair terms");
+        if (c.k > kLambdaFusedMaxK) RL_HIP(t->pool.alloc(&t->d_T, (size_t)N * c.k));
+        RL_HIP(hipDeviceSynchronize());
+        int rc = launch_rank(t, d, c.scores, d.d_ndcg, true);      // ranking of the all-zero start scores (file order)
+        if (rc) return rc;
+    }
     RL_HIP(hipDeviceSynchronize());
     t->inited = true;
     return RL_OK;
@@ -719,7 +752,7 @@ static int final_score(rl_trainer *t, DataSet &d, double *out)
     RL_HIP(t->pool.alloc(&d_sc, (size_t)d.N));
     hipLaunchKernelGGL(k_ensemble_eval, dim3((unsigned)std::min<int64_t>(8192, (d.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, t->ens,
                        t->ctx.MAXN, t->n_kept, (const float *)d.d_X, d.N, t->F, t->p.learning_rate, (float *)nullptr, d_sc);
-    int rc = launch_ndcg(t, d, d_sc, d.d_ndcg);
+    int rc = launch_rank(t, d, d_sc, d.d_ndcg, false);
     if (rc) return rc;
     hipLaunchKernelGGL(k_double_mean, dim3(1), dim3(64), 0, s, (const double *)d.d_ndcg, d.Q, t->d_mean);
     RL_HIP(hipGetLastError());

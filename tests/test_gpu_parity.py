@@ -274,3 +274,18 @@ def test_exact_parallel_float_chain_equals_serial_chain_and_oracle():
         assert tmo == ma[r]
     assert np.array_equal(o.scores().view(np.int64), sa.view(np.int64))
     print("chain stats (leaf segs, leaf fallbacks, metric segs, metric fallbacks):", st_a)
+
+
+@pytest.mark.parametrize("k", [1, 3, 16, 20, 1000])
+def test_ndcg_cutoffs_fused_and_general_lambda_paths(k):
+    """NDCG@k for k <= 16 runs the LDS-fused lambda kernel, larger k the global-matrix kernels; k >= list length too"""
+    X, lab, qoff = make(5000, 8, "mslr", 31)
+    o, g = pair(X, lab, qoff, n_trees=3, n_leaves=8, k=k)
+    o.init(); g.init()
+    for r in range(3):
+        to, tmo, _, _ = o.round()
+        tg, tmg, _, _ = g.boost_round()
+        assert np.array_equal(g.array("LAMBDA").view(np.int64), o.lambdas().view(np.int64)), (k, r)
+        assert np.array_equal(g.array("WEIGHT").view(np.int64), o.weights().view(np.int64)), (k, r)
+        assert_same_tree(to, tg, X, "k %d round %d" % (k, r))
+        assert tmo == tmg
