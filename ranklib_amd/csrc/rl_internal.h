@@ -45,6 +45,7 @@ struct TreeState {
     int32_t n_nodes, cur, done, taken;
     int32_t qsize, new_left, new_right, n_leaves;
     int32_t E, E2, n_splits, error;
+    int32_t build_left, pad0, pad1, pad2;   // which child of the current split is histogrammed from its samples
     unsigned long long maxabs_bits;   // max |lambda| of the round (bit pattern, monotone for x >= 0)
     long long root_sq;                // sum over all docs of rint(lambda^2 * 2^E2)
     long long sq_left;                // same over the left child being built
