@@ -1,0 +1,161 @@
+package ciir.umass.edu.learning.tree;
+
+import java.nio.ByteBuffer;
+import java.nio.ByteOrder;
+import java.nio.FloatBuffer;
+import java.util.HashMap;
+import java.util.List;
+import java.util.Map;
+import java.util.logging.Logger;
+
+import ciir.umass.edu.learning.DataPoint;
+import ciir.umass.edu.learning.RankList;
+import ciir.umass.edu.learning.Ranker;
+import ciir.umass.edu.metric.MetricScorer;
+import ciir.umass.edu.parsing.ModelLineProducer;
+import ciir.umass.edu.utilities.RankLibError;
+import ciir.umass.edu.utilities.SimpleMath;
+
+/**
+ * Drop-in for RankLib's ciir.umass.edu.learning.tree.LambdaMART (same FQCN, placed ahead of RankLib's jar on the
+ * classpath or compiled into it): RankerFactory's prototype table then hands THIS class to "-ranker 6".
+ * The boosting loop runs on an MI355X through librlhip.so; the model is rebuilt from RankLib's own public
+ * Split / RegressionTree / Ensemble classes, so eval(), model(), save() and loadFromString() behave exactly as
+ * before and model files stay interchangeable in both directions.
+ *
+ * NOT COMPILED IN THIS REPOSITORY (no JDK in the build image).  Written against RankLib 2.10.x sources.
+ */
+public class LambdaMART extends Ranker {
+    private static final Logger logger = Logger.getLogger(LambdaMART.class.getName());
+
+    // same names, types and defaults as the reference (learning/tree/LambdaMART.java:37-42)
+    public static int nTrees = 1000;
+    public static float learningRate = 0.1F;
+    public static int nThreshold = 256;
+    public static int nRoundToStopEarly = 100;
+    public static int nTreeLeaves = 10;
+    public static int minLeafSupport = 1;
+    public static int device = 0;
+
+    protected Ensemble ensemble = null;
+    protected double[] impacts = null;          // read by RFRanker (learning/tree/RFRanker.java:88-91); never written, as in the reference
+    private long handle = 0;
+
+    public LambdaMART() {}
+
+    public LambdaMART(final List<RankList> samples, final int[] features, final MetricScorer scorer) {
+        super(samples, features, scorer);
+    }
+
+    private void upload(final List<RankList> lists, final boolean validation, final Map<String, Integer> qids) {
+        long n = 0;
+        for (final RankList rl : lists) n += rl.size();
+        final FloatBuffer X = ByteBuffer.allocateDirect((int) (n * features.length * 4)).order(ByteOrder.nativeOrder()).asFloatBuffer();
+        final float[] labels = new float[(int) n];
+        final int[] qoff = new int[lists.size() + 1];
+        final int[] qkey = new int[lists.size()];
+        int k = 0;
+        for (int q = 0; q < lists.size(); q++) {
+            final RankList rl = lists.get(q);
+            Integer key = qids.get(rl.getID());                  // equal qid strings share the idealGains cache entry
+            if (key == null) { key = qids.size(); qids.put(rl.getID(), key); }
+            qkey[q] = key;
+            for (int j = 0; j < rl.size(); j++, k++) {
+                final DataPoint dp = rl.get(j);
+                labels[k] = dp.getLabel();
+                for (final int fid : features) X.put(dp.getFeatureValue(fid));     // NaN/missing -> 0 here, as in the reference
+            }
+            qoff[q + 1] = k;
+        }
+        RlHipNative.setData(handle, validation, X, n, features.length, labels, qoff, validation ? null : features, qkey);
+    }
+
+    @Override
+    public void init() {
+        logger.info(() -> "Initializing... ");
+        if (!scorer.name().startsWith("NDCG@")) throw RankLibError.create("rlhip: only NDCG@k is built (got " + scorer.name() + ")");
+        handle = RlHipNative.create(nTrees, nTreeLeaves, nThreshold, minLeafSupport, nRoundToStopEarly, learningRate, scorer.getK(), device);
+        impacts = new double[features.length];
+        final Map<String, Integer> qids = new HashMap<>();
+        upload(samples, false, qids);
+        if (validationSamples != null) upload(validationSamples, true, qids);
+        RlHipNative.init(handle);
+    }
+
+    @Override
+    public void learn() {
+        ensemble = new Ensemble();
+        logger.info(() -> "Training starts...");
+        if (validationSamples != null) printLogLn(new int[] { 7, 9, 9 }, new String[] { "#iter", scorer.name() + "-T", scorer.name() + "-V" });
+        else printLogLn(new int[] { 7, 9 }, new String[] { "#iter", scorer.name() + "-T" });
+        final int cap = 2 * nTreeLeaves - 1;
+        final int[] feature = new int[cap], left = new int[cap], right = new int[cap];
+        final float[] threshold = new float[cap], output = new float[cap], metrics = new float[2];
+        for (int m = 0; m < nTrees; m++) {
+            printLog(new int[] { 7 }, new String[] { Integer.toString(m + 1) });
+            final int r = RlHipNative.boostRound(handle, feature, threshold, left, right, output, metrics);
+            ensemble.add(new RegressionTree(build(0, feature, threshold, left, right, output)), learningRate);
+            printLog(new int[] { 9 }, new String[] { Double.toString(SimpleMath.round(metrics[0], 4)) });
+            if (validationSamples != null) printLog(new int[] { 9 }, new String[] { Double.toString(SimpleMath.round(metrics[1], 4)) });
+            flushLog();
+            if (r < 0) break;                                       // early stop (learning/tree/LambdaMART.java:248)
+        }
+        final double[] fin = RlHipNative.finish(handle);             // rollback + scorer.score(rank(samples))
+        while (ensemble.treeCount() > RlHipNative.numTrees(handle)) ensemble.remove(ensemble.treeCount() - 1);
+        scoreOnTrainingData = fin[0];
+        logger.info(() -> "Finished sucessfully.");
+        logger.info(() -> scorer.name() + " on training data: " + SimpleMath.round(scoreOnTrainingData, 4));
+        if (validationSamples != null) {
+            bestScoreOnValidationData = fin[1];
+            logger.info(() -> scorer.name() + " on validation data: " + SimpleMath.round(bestScoreOnValidationData, 4));
+        }
+        RlHipNative.destroy(handle);
+        handle = 0;
+    }
+
+    private static Split build(final int n, final int[] f, final float[] t, final int[] l, final int[] r, final float[] o) {
+        if (f[n] == -1) { final Split s = new Split(); s.setOutput(o[n]); return s; }      // Split.java:40-48,80-82
+        final Split s = new Split(f[n], t[n], 0);
+        s.setLeft(build(l[n], f, t, l, r, o));
+        s.setRight(build(r[n], f, t, l, r, o));
+        return s;
+    }
+
+    @Override public double eval(final DataPoint dp) { return ensemble.eval(dp); }
+    @Override public Ranker createNew() { return new LambdaMART(); }
+    @Override public String toString() { return ensemble.toString(); }
+    @Override public String name() { return "LambdaMART"; }
+    public Ensemble getEnsemble() { return ensemble; }
+
+    @Override
+    public String model() {                                            // identical text to the reference (:290-301)
+        final StringBuilder output = new StringBuilder();
+        output.append("## " + name() + "\n");
+        output.append("## No. of trees = " + nTrees + "\n");
+        output.append("## No. of leaves = " + nTreeLeaves + "\n");
+        output.append("## No. of threshold candidates = " + nThreshold + "\n");
+        output.append("## Learning rate = " + learningRate + "\n");
+        output.append("## Stop early = " + nRoundToStopEarly + "\n");
+        output.append("\n");
+        output.append(toString());
+        return output.toString();
+    }
+
+    @Override
+    public void loadFromString(final String fullText) {
+        final ModelLineProducer lineByLine = new ModelLineProducer();
+        lineByLine.parse(fullText, (model, endEns) -> {});
+        ensemble = new Ensemble(lineByLine.getModel().toString());
+        features = ensemble.getFeatures();
+    }
+
+    @Override
+    public void printParameters() {
+        logger.info(() -> "No. of trees: " + nTrees);
+        logger.info(() -> "No. of leaves: " + nTreeLeaves);
+        logger.info(() -> "No. of threshold candidates: " + nThreshold);
+        logger.info(() -> "Min leaf support: " + minLeafSupport);
+        logger.info(() -> "Learning rate: " + learningRate);
+        logger.info(() -> "Stop early: " + nRoundToStopEarly + " rounds without performance gain on validation data");
+    }
+}

@@ -1,0 +1,17 @@
+package ciir.umass.edu.learning.tree;
+
+import java.nio.FloatBuffer;
+
+/** static native methods bound by integration/jni/RlHipNative.c to librlhip.so (include/rlhip.h). */
+final class RlHipNative {
+    static { System.loadLibrary("rlhipjni"); }
+    private RlHipNative() {}
+    static native long create(int nTrees, int nLeaves, int nThreshold, int minLeafSupport, int stopEarly, float lr, int k, int device);
+    static native void destroy(long h);
+    static native int setData(long h, boolean validation, FloatBuffer X, long nDocs, int nFeatures, float[] labels, int[] qoff,
+            int[] featureIds, int[] qkey);
+    static native int init(long h);
+    static native int boostRound(long h, int[] feature, float[] threshold, int[] left, int[] right, float[] output, float[] metrics);
+    static native double[] finish(long h);
+    static native int numTrees(long h);
+}
