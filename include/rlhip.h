@@ -163,6 +163,18 @@ int rl_dist_unique_id(void *id_out /* RL_UNIQUE_ID_BYTES */);       /* call on r
  * per-split histograms (and the few per-round scalars) are summed across ranks with RCCL. */
 int rl_dist_init(rl_trainer *t, const void *id, int32_t rank, int32_t n_ranks);
 
+/* The same sharded training over a caller-supplied transport instead of RCCL (gloo, MPI, shared memory ...):
+ * the library stages each exchange through host memory and calls back.  Slower (a host synchronisation per
+ * exchange); used by the tests to run several ranks on ONE GPU and prove k shards == 1 shard bit for bit.
+ * dtype: RL_DT_*, op: RL_OP_*; all-reduce is in place on `host_buf`; all-gather writes n_ranks*bytes to `out`.
+ * Callbacks return 0 on success. */
+enum { RL_DT_I64 = 0, RL_DT_U64 = 1, RL_DT_I32 = 2, RL_DT_U32 = 3, RL_DT_F64 = 4 };
+enum { RL_OP_SUM = 0, RL_OP_MAX = 1, RL_OP_MIN = 2 };
+typedef int (*rl_host_allreduce_fn)(void *user, void *host_buf, int64_t count, int32_t dtype, int32_t op);
+typedef int (*rl_host_allgather_fn)(void *user, const void *in, void *out, int64_t bytes_per_rank);
+int rl_dist_init_callback(rl_trainer *t, int32_t rank, int32_t n_ranks, rl_host_allreduce_fn allreduce,
+                          rl_host_allgather_fn allgather, void *user);
+
 /* ---- introspection for parity tests and the roofline report ------------------------------- */
 enum {
     RL_ARR_LAMBDA = 1,       /* double[n_docs]  pseudoResponses of the last round */

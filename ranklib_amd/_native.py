@@ -41,9 +41,13 @@ ABI_SYMBOLS = [
     "rl_set_train", "rl_set_validation", "rl_init", "rl_boost_round", "rl_boost_rounds_async", "rl_sync",
     "rl_finish", "rl_num_trees", "rl_get_tree", "rl_get_round_metrics", "rl_best_validation", "rl_predict",
     "rl_model_to_text", "rl_model_from_text", "rl_model_destroy", "rl_model_num_trees", "rl_model_features",
-    "rl_model_predict", "rl_dist_unique_id", "rl_dist_init", "rl_bin_stride", "rl_quant_exponent", "rl_get_array",
+    "rl_model_predict", "rl_dist_unique_id", "rl_dist_init", "rl_dist_init_callback", "rl_bin_stride", "rl_quant_exponent", "rl_get_array",
     "rl_get_timing", "rl_reset_timing",
 ]
+
+HOST_ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32)
+HOST_ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+DT_NUMPY = {0: np.int64, 1: np.uint64, 2: np.int32, 3: np.uint32, 4: np.float64}
 
 _lib = None
 
@@ -87,6 +91,7 @@ def lib():
     L.rl_model_predict.argtypes = [vp, vp, i64, i32, vp]
     L.rl_dist_unique_id.argtypes = [vp]
     L.rl_dist_init.argtypes = [vp, vp, i32, i32]
+    L.rl_dist_init_callback.argtypes = [vp, i32, i32, HOST_ALLREDUCE, HOST_ALLGATHER, vp]
     L.rl_bin_stride.argtypes = [vp, C.POINTER(i32)]
     L.rl_quant_exponent.argtypes = [vp, C.POINTER(i32)]
     L.rl_get_array.argtypes = [vp, i32, vp, i64]
@@ -179,6 +184,39 @@ class Trainer:
         check(lib().rl_set_validation(self.h, X.ctypes.data, self.Nv, labels.ctypes.data, qoff.ctypes.data,
                                       len(qoff) - 1, None if qk is None else qk.ctypes.data))
         self.has_valid = True
+
+    def dist_unique_id(self):
+        """128 bytes for ncclCommInitRank: call on rank 0, broadcast out of band"""
+        buf = C.create_string_buffer(128)
+        check(lib().rl_dist_unique_id(buf))
+        return buf.raw
+
+    def dist_init(self, uid, rank, n_ranks):
+        """RCCL transport; every rank passes ITS shard of the queries to set_train (before init)"""
+        check(lib().rl_dist_init(self.h, uid, rank, n_ranks))
+
+    def dist_init_callback(self, rank, n_ranks, allreduce, allgather):
+        """host transport: allreduce(np_array, op) reduces in place, allgather(np_uint8_in) -> np_uint8 [n_ranks*len]"""
+        def _ar(user, ptr, count, dtype, op):
+            try:
+                arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), (count * np.dtype(DT_NUMPY[dtype]).itemsize,)).view(DT_NUMPY[dtype])
+                allreduce(arr, op)
+                return 0
+            except Exception as e:          # noqa: BLE001 -- must not propagate through the C frame
+                print("host all-reduce callback failed:", e)
+                return 1
+
+        def _ag(user, pin, pout, nbytes):
+            try:
+                src = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint8)), (nbytes,))
+                dst = np.ctypeslib.as_array(C.cast(pout, C.POINTER(C.c_uint8)), (nbytes * n_ranks,))
+                dst[:] = allgather(src)
+                return 0
+            except Exception as e:          # noqa: BLE001
+                print("host all-gather callback failed:", e)
+                return 1
+        self._cb = (HOST_ALLREDUCE(_ar), HOST_ALLGATHER(_ag))      # keep alive
+        check(lib().rl_dist_init_callback(self.h, rank, n_ranks, self._cb[0], self._cb[1], None))
 
     def init(self):
         check(lib().rl_init(self.h))

@@ -38,7 +38,7 @@ struct NodeRec {
     double  sq_response;     // node total of lambda^2
     long long tot_hi; unsigned long long tot_lo;   // exact 128-bit fixed-point sum of lambda
     long long sq;            // exact fixed-point sum of lambda^2
-    float   output; int32_t pad;
+    float   output; int32_t gcount;   // gcount: samples of the node over ALL ranks (== count on one GPU)
 };
 
 struct TreeState {
@@ -60,6 +60,7 @@ struct Ctx {
     int32_t N, Npad, Q, F, TS, L, MAXN, mls, k, maxChunks, nTiles, FG, numFG;
     float lr;
     int32_t rank, n_ranks;
+    long long *dist_buf;     // [F*TS*3 + 4] int64 limbs of the histogram being all-reduced (multi-GPU only)
     // static per data set
     const uint16_t *bins;   // [F][Npad]
     const float *thr;       // [F][TS]

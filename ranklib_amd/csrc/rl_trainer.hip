@@ -18,6 +18,7 @@
 #include "rl_kernels_init.inc"
 #include "rl_chain.inc"
 #include "rl_kernels_round.inc"
+#include "rl_dist.inc"
 #include "rl_model.h"
 
 namespace rl {
@@ -87,8 +88,14 @@ struct rl_trainer {
     std::vector<double> ev_bytes[RL_KERNEL_COUNT_];
     std::vector<hipEvent_t> ev_free;
     TimingSlot timing[RL_KERNEL_COUNT_];
-    // distributed
+    // distributed (rl_dist.inc)
     int32_t rank = 0, n_ranks = 1;
+    std::unique_ptr<DistBackend> dist;
+    std::vector<int32_t> all_N, all_Q;        // local sizes of every rank
+    int64_t Nglobal = 0; int32_t Qglobal = 0, Qmax = 0;
+    ChainBufs gchain;                          // float chains over the all-gathered leaf values
+    double *d_gx = nullptr; int32_t *d_gls = nullptr; int32_t lsstride = 0;
+    double *d_qsend = nullptr, *d_qgath = nullptr, *d_qcat = nullptr; int32_t *d_allQ = nullptr;
 };
 
 namespace rl {
@@ -272,6 +279,18 @@ static int launch_rank(rl_trainer *t, DataSet &d, const double *scores, double *
     return RL_OK;
 }
 
+// multi-GPU: per-query values of all ranks in global query order (ranks hold ascending contiguous query ranges)
+static int gather_queries(rl_trainer *t, const double *local, const double **out)
+{
+    hipStream_t s = t->stream;
+    hipLaunchKernelGGL(k_copy_f64, dim3(std::max(1, std::min(1024, (t->tr.Q + kThreads - 1) / kThreads))), dim3(kThreads), 0, s, local, t->d_qsend, t->tr.Q);
+    int rc = t->dist->allgather(t->d_qsend, t->d_qgath, (size_t)t->Qmax * sizeof(double), s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_concat_ranks, dim3(64), dim3(kThreads), 0, s, (const double *)t->d_qgath, (const int32_t *)t->d_allQ, t->n_ranks, t->Qmax, t->d_qcat);
+    *out = t->d_qcat;
+    return RL_OK;
+}
+
 static int enqueue_round(rl_trainer *t)
 {
     Ctx &c = t->ctx;
@@ -295,6 +314,7 @@ static int enqueue_round(rl_trainer *t)
             hipLaunchKernelGGL(k_lambda_acc, dim3(nb), dim3(kThreads), 0, s, g);
         }
     }
+    if (t->dist) { int rcd = t->dist->allreduce(&c.st->maxabs_bits, 1, DT_U64, OP_MAX, s); if (rcd) return rcd; }
     hipLaunchKernelGGL(k_quantize, dim3(std::min(2048, (c.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, c);
     const size_t hist_lds = (size_t)c.FG * c.TS * 12;
     const size_t fin_lds = (size_t)c.TS * 20;
@@ -305,7 +325,12 @@ static int enqueue_round(rl_trainer *t)
         if (c.FG == kHistFG) hipLaunchKernelGGL((k_hist<true, kHistFG>), dim3(c.numFG, rootChunks), dim3(kThreads), hist_lds, s, c);
         else hipLaunchKernelGGL((k_hist<true, 1>), dim3(c.numFG, rootChunks), dim3(kThreads), hist_lds, s, c);
     }
-    hipLaunchKernelGGL(k_hist_finish<true>, dim3(c.F), dim3(kThreads), fin_lds, s, c);
+    if (t->dist) {
+        hipLaunchKernelGGL(k_hist_reduce, dim3(c.F), dim3(kThreads), 0, s, c, 1);
+        int rcd = t->dist->allreduce(c.dist_buf, (size_t)c.F * c.TS * 3 + 4, DT_I64, OP_SUM, s);
+        if (rcd) return rcd;
+        hipLaunchKernelGGL((k_hist_finish<true, true>), dim3(c.F), dim3(kThreads), fin_lds, s, c);
+    } else hipLaunchKernelGGL((k_hist_finish<true, false>), dim3(c.F), dim3(kThreads), fin_lds, s, c);
     hipLaunchKernelGGL(k_select, dim3(1), dim3(64), 0, s, c, 1);
     const int steps = c.L - 1;
     for (int it = 0; it < steps; it++) {
@@ -316,12 +341,32 @@ static int enqueue_round(rl_trainer *t)
             if (c.FG == kHistFG) hipLaunchKernelGGL((k_hist<false, kHistFG>), dim3(c.numFG, c.maxChunks), dim3(kThreads), hist_lds, s, c);
             else hipLaunchKernelGGL((k_hist<false, 1>), dim3(c.numFG, c.maxChunks), dim3(kThreads), hist_lds, s, c);
         }
-        hipLaunchKernelGGL(k_hist_finish<false>, dim3(c.F), dim3(kThreads), fin_lds, s, c);
+        if (t->dist) {
+            hipLaunchKernelGGL(k_hist_reduce, dim3(c.F), dim3(kThreads), 0, s, c, 0);
+            int rcd = t->dist->allreduce(c.dist_buf, (size_t)c.F * c.TS * 3 + 4, DT_I64, OP_SUM, s);
+            if (rcd) return rcd;
+            hipLaunchKernelGGL((k_hist_finish<false, true>), dim3(c.F), dim3(kThreads), fin_lds, s, c);
+        } else hipLaunchKernelGGL((k_hist_finish<false, false>), dim3(c.F), dim3(kThreads), fin_lds, s, c);
         hipLaunchKernelGGL(k_select, dim3(1), dim3(64), 0, s, c, 0);
     }
     hipLaunchKernelGGL(k_leaf_table, dim3(1), dim3(64), 0, s, c, t->leaf_chain, t->d_seg_buf);
     if (t->p.flags & RL_FLAG_SERIAL_CHAIN) {
         hipLaunchKernelGGL(k_leaf_chain, dim3(c.L), dim3(64), 0, s, c);
+    } else if (t->dist) {
+        // multi-GPU: gather lambda / weight in leaf order from every rank and evaluate the chains over the whole leaf
+        ChainSource src{c.lambda, c.weight, c.idx[0], c.idx[1], t->d_seg_buf};
+        const ChainBufs &lb = t->leaf_chain;
+        hipLaunchKernelGGL(k_chain_prefix, dim3((unsigned)((lb.cap_tiles + 3) / 4), lb.A), dim3(kThreads), 0, s, lb, src);
+        int rcd = t->dist->allgather(lb.xs, t->d_gx, (size_t)lb.A * lb.cap_n * sizeof(double), s);
+        if (rcd) return rcd;
+        rcd = t->dist->allgather(c.leaf_start, t->d_gls, (size_t)t->lsstride * sizeof(int32_t), s);
+        if (rcd) return rcd;
+        hipLaunchKernelGGL(k_plan_global, dim3(1), dim3(64), 0, s, (const int32_t *)t->d_gls, t->n_ranks, t->lsstride, c.L, t->gchain);
+        hipLaunchKernelGGL(k_chain_assemble, dim3(c.L, 2), dim3(kThreads), 0, s, (const double *)t->d_gx, (const int32_t *)t->d_gls, t->n_ranks, 2,
+                           (int)lb.cap_n, t->lsstride, c.L, t->gchain);
+        ChainSource gsrc{t->gchain.xs, t->gchain.xs + t->gchain.cap_n, nullptr, nullptr, nullptr};
+        enqueue_chain(t, t->gchain, gsrc);
+        hipLaunchKernelGGL(k_leaf_output, dim3((c.L + kThreads - 1) / kThreads), dim3(kThreads), 0, s, c, t->gchain);
     } else {   // K7: the two Java float running sums of every leaf, exactly, in parallel (rl_chain.inc)
         ChainSource src{c.lambda, c.weight, c.idx[0], c.idx[1], t->d_seg_buf};
         enqueue_chain(t, t->leaf_chain, src);
@@ -333,7 +378,12 @@ static int enqueue_round(rl_trainer *t)
     // per-round training metric (LambdaMART.java:216)
     int rc = launch_rank(t, t->tr, c.scores, t->tr.d_ndcg, true);      // also the ranking of round m+1's lambdas
     if (rc != RL_OK) return rc;
-    enqueue_metric_mean(t, t->tr.d_ndcg, t->tr.Q, c.round_metric + 2 * (size_t)m);
+    if (t->dist) {
+        const double *gq = nullptr;
+        rc = gather_queries(t, t->tr.d_ndcg, &gq);
+        if (rc != RL_OK) return rc;
+        enqueue_metric_mean(t, gq, t->Qglobal, c.round_metric + 2 * (size_t)m);
+    } else enqueue_metric_mean(t, t->tr.d_ndcg, t->tr.Q, c.round_metric + 2 * (size_t)m);
     if (t->has_valid) {   // :228-237
         hipLaunchKernelGGL(k_valid_update, dim3(std::min<int64_t>(4096, (t->va.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
                            t->ens, c.MAXN, m, (const float *)t->va.d_X, (int)t->va.N, c.F, c.lr, t->va.d_scores);
@@ -476,8 +526,10 @@ int rl_create(const rl_params *p, rl_trainer **out)
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, kHistFG>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
-    RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
-    RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
     RL_HIP(hipFuncSetAttribute((const void *)k_rank_block, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaBlockCap * 12));
     RL_HIP(hipFuncSetAttribute((const void *)k_lambda_fused<256>, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaFusedMaxK * 256 * 16 + 2048));
     RL_HIP(hipFuncSetAttribute((const void *)k_chain_stitch, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -568,6 +620,21 @@ int rl_init(rl_trainer *t)
     const int slices = std::max(1, std::min(64, N / 4096));
     hipLaunchKernelGGL(k_feat_stats, dim3(F, slices), dim3(kThreads), fs.HS * sizeof(uint32_t), s, (const float *)Xt, N, Npad, fs);
     RL_HIP(hipGetLastError());
+    if (t->dist) {      // global min / max / distinct sets: every rank must build the same threshold table
+        int rcd = t->dist->allreduce(fs.minkey, F, DT_U32, OP_MIN, s); if (rcd) return rcd;
+        rcd = t->dist->allreduce(fs.maxkey, F, DT_U32, OP_MAX, s); if (rcd) return rcd;
+        rcd = t->dist->allreduce(fs.overflow, F, DT_I32, OP_MAX, s); if (rcd) return rcd;
+        rcd = t->dist->allreduce(fs.bad, 1, DT_I32, OP_MAX, s); if (rcd) return rcd;
+        uint32_t *gsets = nullptr;
+        RL_HIP(t->pool.alloc(&gsets, (size_t)t->n_ranks * F * fs.HS));
+        rcd = t->dist->allgather(fs.set, gsets, (size_t)F * fs.HS * sizeof(uint32_t), s); if (rcd) return rcd;
+        RL_HIP(hipMemsetAsync(fs.set, 0, (size_t)F * fs.HS * sizeof(uint32_t), s));
+        RL_HIP(hipMemsetAsync(fs.nset, 0, F * sizeof(int32_t), s));
+        hipLaunchKernelGGL(k_merge_sets, dim3(F, t->n_ranks), dim3(kThreads), 0, s, (const uint32_t *)gsets, t->n_ranks, fs);
+        RL_HIP(hipGetLastError());
+        RL_HIP(hipStreamSynchronize(s));
+        t->pool.release(gsets);
+    }
     std::vector<int32_t> h_over(F);
     int32_t h_bad = 0;
     RL_HIP(hipStreamSynchronize(s));
@@ -610,6 +677,7 @@ int rl_init(rl_trainer *t)
     RL_HIP(hipMemsetAsync(c.cum_cnt, 0, (size_t)F * TS * sizeof(int32_t), s));
     hipLaunchKernelGGL(k_binning, dim3(F, slices), dim3(kThreads), (size_t)TS * 8, s, (const float *)Xt, N, Npad, TS, (const float *)d_thr,
                        (const int32_t *)d_nthr, d_bins, c.cum_cnt);
+    if (t->dist) { int rcd = t->dist->allreduce(c.cum_cnt, (size_t)F * TS, DT_I32, OP_SUM, s); if (rcd) return rcd; }
     hipLaunchKernelGGL(k_cumulate_counts, dim3(F), dim3(64), 0, s, TS, (const int32_t *)d_nthr, c.cum_cnt);
     RL_HIP(hipGetLastError());
     RL_HIP(hipStreamSynchronize(s));
@@ -678,11 +746,44 @@ int rl_init(rl_trainer *t)
     RL_HIP(hipMemset(t->ens.n_nodes, 0, t->p.n_trees * sizeof(int32_t)));
     RL_HIP(t->pool.alloc(&t->d_mean, (size_t)2));
     {
-        int rc = alloc_chain(t, t->leaf_chain, c.MAXN + 1, 2, N);
+        int64_t Nmax = N;
+        t->Qglobal = t->tr.Q; t->Qmax = t->tr.Q; t->Nglobal = N;
+        if (t->dist) {      // sizes of every rank
+            if (t->has_valid) return fail(RL_ERR_UNSUPPORTED, "validation data with multi-GPU training is not built yet");
+            int32_t *d_sz = nullptr, *d_all = nullptr;
+            RL_HIP(t->pool.alloc(&d_sz, (size_t)2)); RL_HIP(t->pool.alloc(&d_all, (size_t)2 * t->n_ranks));
+            const int32_t mine[2] = {N, t->tr.Q};
+            RL_HIP(hipMemcpy(d_sz, mine, sizeof(mine), hipMemcpyHostToDevice));
+            int rcd = t->dist->allgather(d_sz, d_all, sizeof(mine), s); if (rcd) return rcd;
+            std::vector<int32_t> all((size_t)2 * t->n_ranks);
+            RL_HIP(hipStreamSynchronize(s));
+            RL_HIP(hipMemcpy(all.data(), d_all, all.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            t->all_N.clear(); t->all_Q.clear(); t->Nglobal = 0; t->Qglobal = 0; t->Qmax = 0;
+            for (int r = 0; r < t->n_ranks; r++) {
+                t->all_N.push_back(all[2 * r]); t->all_Q.push_back(all[2 * r + 1]);
+                t->Nglobal += all[2 * r]; t->Qglobal += all[2 * r + 1];
+                Nmax = std::max<int64_t>(Nmax, all[2 * r]); t->Qmax = std::max(t->Qmax, all[2 * r + 1]);
+            }
+            if (t->Nglobal >= (int64_t)2147483647 - 4096) return fail(RL_ERR_UNSUPPORTED, "more than 2^31 documents in total");
+        }
+        int rc = alloc_chain(t, t->leaf_chain, c.MAXN + 1, 2, Nmax);
         if (rc) return rc;
-        rc = alloc_chain(t, t->metric_chain, 1, 1, std::max(t->tr.Q, t->has_valid ? t->va.Q : 0));
+        rc = alloc_chain(t, t->metric_chain, 1, 1, std::max(t->Qglobal, t->has_valid ? t->va.Q : 0));
         if (rc) return rc;
         RL_HIP(t->pool.alloc(&t->d_seg_buf, (size_t)c.MAXN + 2));
+        if (t->dist) {
+            rc = alloc_chain(t, t->gchain, c.MAXN + 1, 2, t->Nglobal);
+            if (rc) return rc;
+            t->lsstride = c.MAXN + 2;
+            RL_HIP(t->pool.alloc(&t->d_gx, (size_t)t->n_ranks * 2 * t->leaf_chain.cap_n));
+            RL_HIP(t->pool.alloc(&t->d_gls, (size_t)t->n_ranks * t->lsstride));
+            RL_HIP(t->pool.alloc(&t->d_qsend, (size_t)t->Qmax)); RL_HIP(t->pool.alloc(&t->d_qgath, (size_t)t->n_ranks * t->Qmax));
+            RL_HIP(t->pool.alloc(&t->d_qcat, (size_t)t->Qglobal)); RL_HIP(t->pool.alloc(&t->d_allQ, (size_t)t->n_ranks));
+            RL_HIP(hipMemcpy(t->d_allQ, t->all_Q.data(), t->n_ranks * sizeof(int32_t), hipMemcpyHostToDevice));
+            RL_HIP(hipMemset(t->d_qsend, 0, (size_t)t->Qmax * sizeof(double)));
+            RL_HIP(t->pool.alloc(&c.dist_buf, (size_t)F * TS * 3 + 4));
+            RL_HIP(hipMemset(c.dist_buf, 0, ((size_t)F * TS * 3 + 4) * sizeof(long long)));
+        }
     }
     {   // ranked-order arrays + pair-term matrix of the lambda kernels
         DataSet &d = t->tr;
@@ -754,7 +855,12 @@ static int final_score(rl_trainer *t, DataSet &d, double *out)
                        t->ctx.MAXN, t->n_kept, (const float *)d.d_X, d.N, t->F, t->p.learning_rate, (float *)nullptr, d_sc);
     int rc = launch_rank(t, d, d_sc, d.d_ndcg, false);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_double_mean, dim3(1), dim3(64), 0, s, (const double *)d.d_ndcg, d.Q, t->d_mean);
+    if (t->dist) {
+        const double *gq = nullptr;
+        rc = gather_queries(t, d.d_ndcg, &gq);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_double_mean, dim3(1), dim3(64), 0, s, gq, t->Qglobal, t->d_mean);
+    } else hipLaunchKernelGGL(k_double_mean, dim3(1), dim3(64), 0, s, (const double *)d.d_ndcg, d.Q, t->d_mean);
     RL_HIP(hipGetLastError());
     RL_HIP(hipStreamSynchronize(s));
     RL_HIP(hipMemcpy(out, t->d_mean, sizeof(double), hipMemcpyDeviceToHost));
@@ -865,12 +971,54 @@ int rl_model_to_text(const rl_trainer *t, char *buf, int64_t cap, int64_t *neede
     return RL_OK;
 }
 
-// ---- multi-GPU: filled in by rl_dist.hip when built with RCCL -------------------------------------
-int rl_dist_unique_id(void *id_out) { (void)id_out; return fail(RL_ERR_UNSUPPORTED, "multi-GPU path not built yet"); }
+// ---- multi-GPU (rl_dist.inc) -------------------------------------------------------------------------
+int rl_dist_unique_id(void *id_out)
+{
+    if (!id_out) return fail(RL_ERR_INVALID, "null id buffer");
+    RcclApi &r = rccl();
+    if (!r.lib || !r.GetUniqueId) return fail(RL_ERR_COMM, "librccl.so could not be loaded");
+    const int rc = r.GetUniqueId(id_out);
+    return rc == 0 ? RL_OK : fail(RL_ERR_COMM, std::string("ncclGetUniqueId: ") + r.GetErrorString(rc));
+}
+
+static int dist_precheck(rl_trainer *t, int32_t rank, int32_t n_ranks)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    if (t->inited) return fail(RL_ERR_STATE, "rl_dist_init must be called before rl_init");
+    if (n_ranks < 1 || n_ranks > 64 || rank < 0 || rank >= n_ranks) return fail(RL_ERR_INVALID, "bad rank / n_ranks (1..64 ranks)");
+    return RL_OK;
+}
+
 int rl_dist_init(rl_trainer *t, const void *id, int32_t rank, int32_t n_ranks)
 {
-    (void)t; (void)id; (void)rank; (void)n_ranks;
-    return fail(RL_ERR_UNSUPPORTED, "multi-GPU path not built yet");
+    int rc = dist_precheck(t, rank, n_ranks);
+    if (rc) return rc;
+    if (!id) return fail(RL_ERR_INVALID, "null unique id");
+    RL_HIP(hipSetDevice(t->p.device));
+    RcclApi &r = rccl();
+    if (!r.lib || !r.CommInitRank || !r.AllReduce || !r.AllGather) return fail(RL_ERR_COMM, "librccl.so could not be loaded");
+    std::unique_ptr<RcclBackend> b(new RcclBackend());
+    UidVal u;
+    memcpy(u.b, id, RL_UNIQUE_ID_BYTES);
+    const int nrc = r.CommInitRank(&b->comm, n_ranks, u, rank);
+    if (nrc != 0) return fail(RL_ERR_COMM, std::string("ncclCommInitRank: ") + r.GetErrorString(nrc));
+    b->rank = rank; b->n = n_ranks;
+    t->rank = rank; t->n_ranks = n_ranks;
+    t->dist = std::move(b);
+    return RL_OK;
+}
+
+int rl_dist_init_callback(rl_trainer *t, int32_t rank, int32_t n_ranks, rl_host_allreduce_fn allreduce, rl_host_allgather_fn allgather,
+                          void *user)
+{
+    int rc = dist_precheck(t, rank, n_ranks);
+    if (rc) return rc;
+    if (!allreduce || !allgather) return fail(RL_ERR_INVALID, "null callback");
+    std::unique_ptr<CallbackBackend> b(new CallbackBackend());
+    b->ar = allreduce; b->ag = allgather; b->user = user; b->rank = rank; b->n = n_ranks;
+    t->rank = rank; t->n_ranks = n_ranks;
+    t->dist = std::move(b);
+    return RL_OK;
 }
 
 // ---- introspection -------------------------------------------------------------------------------

@@ -1,0 +1,47 @@
+"""Worker of tests/test_gpu_dist.py: one rank of a k-rank sharded training run on ONE GPU.
+Launched with torch.distributed.run; transport = host callbacks over gloo."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    from ranklib_amd import _native as N
+    from ranklib_amd import dist as D
+    from ranklib_amd import synth
+
+    out_path, n_docs, n_feat, kind, seed, leaves, rounds = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    X, lab, qoff = synth.make_dataset(n_docs, n_feat, kind, seed_offset=seed)
+    Xs, ls, qs = D.shard(X, lab, qoff, rank, world)
+    tr = D.TorchHostTransport()
+    g = N.Trainer(n_trees=rounds, n_leaves=leaves)
+    g.set_train(Xs, ls, qs)
+    g.dist_init_callback(rank, world, tr.allreduce, tr.allgather)
+    g.init()
+    trees, mets = [], []
+    for _ in range(rounds):
+        t, tm, _, _ = g.boost_round()
+        trees.append(t.trimmed()); mets.append(float(tm))
+    final, _ = g.finish()
+    sc = g.array("SCORE")
+    parts = [None] * world
+    dist.all_gather_object(parts, sc)
+    stats = g.array("CHAIN_STATS")
+    if rank == 0:
+        np.savez(out_path, scores=np.concatenate(parts), mets=np.array(mets), final=final, stats=stats,
+                 **{"t%d_%s" % (i, k): v for i, t in enumerate(trees) for k, v in t.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

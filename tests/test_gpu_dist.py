@@ -1,0 +1,73 @@
+"""-m gpu: multi-rank (sharded) training == single-GPU training, bit for bit.
+
+Only one GPU is available to the tests, so k ranks run as k processes on the SAME device and exchange through the
+host-callback transport over gloo (rl_dist_init_callback).  Every rank executes exactly the code path an RCCL rank
+executes (k_hist_reduce -> all-reduce of int64 limbs -> k_hist_finish<.,true>, global thresholds, local/global
+node counts, gathered float chains); only the transport differs.  The RCCL transport itself is exercised with a
+1-rank communicator.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from ranklib_amd import _native as N
+from ranklib_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def single(n_docs, n_feat, kind, seed, leaves, rounds, dist_mode=None):
+    X, lab, qoff = synth.make_dataset(n_docs, n_feat, kind, seed_offset=seed)
+    g = N.Trainer(n_trees=rounds, n_leaves=leaves)
+    g.set_train(X, lab, qoff)
+    if dist_mode == "rccl1":
+        g.dist_init(g.dist_unique_id(), 0, 1)
+    elif dist_mode == "cb1":
+        g.dist_init_callback(0, 1, lambda arr, op: None, lambda src: src.copy())
+    g.init()
+    trees, mets = [], []
+    for _ in range(rounds):
+        t, tm, _, _ = g.boost_round()
+        trees.append(t.trimmed()); mets.append(float(tm))
+    final, _ = g.finish()
+    return trees, mets, g.array("SCORE"), final
+
+
+def same(a, b):
+    ta, ma, sa, fa = a
+    tb, mb, sb, fb = b
+    assert ma == mb and fa == fb
+    assert np.array_equal(sa.view(np.int64), sb.view(np.int64))
+    for x, y in zip(ta, tb):
+        for k in ("feature", "left", "right", "count"):
+            assert np.array_equal(x[k], y[k]), k
+        assert np.array_equal(x["threshold"].view(np.uint32), y["threshold"].view(np.uint32))
+        assert np.array_equal(x["output"].view(np.uint32), y["output"].view(np.uint32))
+
+
+CFG = (9000, 24, "mslr", 3, 12, 5)
+
+
+def test_one_rank_distributed_paths_equal_plain_path():
+    ref = single(*CFG)
+    same(ref, single(*CFG, dist_mode="cb1"))       # host-callback transport, 1 rank
+    same(ref, single(*CFG, dist_mode="rccl1"))     # RCCL transport (dlopen'ed librccl), 1-rank communicator
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_k_shards_equal_one_shard(world, tmp_path):
+    ref = single(*CFG)
+    out = str(tmp_path / "dist.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29511 + world), os.path.join(ROOT, "tests", "dist_worker.py"), out] + [str(v) for v in CFG]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    z = np.load(out)
+    rounds = CFG[5]
+    trees = [{k: z["t%d_%s" % (i, k)] for k in ("feature", "threshold", "left", "right", "output", "deviance", "count")} for i in range(rounds)]
+    same(ref, (trees, [float(v) for v in z["mets"]], z["scores"], float(z["final"])))
