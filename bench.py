@@ -3,8 +3,13 @@
 
 A "step" is one boosting round (one iteration of learning/tree/LambdaMART.java:180-251: lambdas,
 root histogram, a 31-leaf tree grown best-first, leaf outputs, score update, train NDCG@10) on synthetic
-MSLR-WEB10K-shaped data that is already resident in HBM when the timed region starts (init() -- binning,
+MSLR-shaped data that is already resident in HBM when the timed region starts (init() -- binning,
 H2D -- is reported separately, never inside `value`).
+
+Workload: the shape BASELINE.json's metric is quoted on, MSLR-WEB30K-shape (configs[2]: 3.77 M documents x 136
+features, ~31.5 k queries, 31 leaves); it fits one GPU, so N = 1 runs the whole set and N > 1 shards the SAME
+set's queries contiguously over the ranks ("scaling": "strong"; one exact histogram all-reduce per split over
+RCCL).  `--shape c1` runs configs[1] (MSLR-WEB10K-shape, 1.2 M documents).
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...    (queries sharded by rank)
@@ -32,7 +37,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--shape", default="c1", help="c0 | c1 | c1ns | c2 (ranklib_amd.synth.SHAPES)")
+    ap.add_argument("--shape", default="c2", help="c0 | c1 | c1ns | c2 (ranklib_amd.synth.SHAPES)")
     ap.add_argument("--cpu-rounds", type=int, default=8, help="rounds timed for the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores (RankLib's default -thread)")
     ap.add_argument("--no-timing", action="store_true", help="do not record HIP events around the dominant kernel")
@@ -54,16 +59,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
+        # control plane only (rendezvous, unique-id broadcast, timing max): gloo.  The data path (histogram
+        # all-reduce, gathers) is the library's own RCCL communicator over xGMI.
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo")
 
     n_docs, n_feat, kind, n_trees, n_leaves = synth.SHAPES[args.shape]
     t0 = time.time()
-    if world == 1:
-        X, lab, qoff = synth.make_dataset(n_docs, n_feat, kind)
-    else:
-        # weak scaling: every rank holds a full-size shard of its own queries (different seeds per rank)
-        X, lab, qoff = synth.make_dataset(n_docs, n_feat, kind, seed_offset=1000 * rank)
+    X, lab, qoff, q_total = synth.make_shard(n_docs, n_feat, kind, rank, world)
     t_gen = time.time() - t0
 
     flags = 0 if args.no_timing else N.RL_FLAG_TIMING
@@ -72,11 +75,9 @@ def main():
     t0 = time.time()
     g.set_train(X, lab, qoff)
     if world > 1:
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            uid = torch.frombuffer(bytearray(g.dist_unique_id()), dtype=torch.uint8).cuda()
-        dist.broadcast(uid, 0)
-        g.dist_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+        box = [g.dist_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        g.dist_init(box[0], rank, world)
     g.init()
     t_init = time.time() - t0
 
@@ -96,7 +97,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -117,15 +118,17 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong",
         "vs_baseline": None,
         "dtype": "int64 fixed-point histograms + f64 lambdas/scores (f32 leaf chains as in the Java)",
         "data": "synthetic",
         "config": {
-            "workload": "BASELINE.json configs[1]: MSLR-WEB10K-shape %s: %d docs x %d features, %d queries (%s docs/query), "
-                        "%d leaves, lr 0.1, -tc 256, -mls 1, NDCG@10; per GPU" %
-                        (args.shape, n_docs, n_feat, len(qoff) - 1, "~120 log-normal" if kind == "mslr" else "5..15", n_leaves),
-            "docs_per_gpu": n_docs, "features": n_feat, "queries_per_gpu": int(len(qoff) - 1), "leaves": n_leaves,
+            "workload": "%s: synthetic %s, %d docs x %d features, %d queries (%s docs/query) in total, queries sharded "
+                        "contiguously over %d GPU(s); LambdaMART -ranker 6, %d leaves, lr 0.1, -tc 256, -mls 1, NDCG@10" %
+                        (args.shape, {"c2": "MSLR-WEB30K-shape (BASELINE.json configs[2], the shape the metric is quoted on)",
+                                      "c1": "MSLR-WEB10K-shape (BASELINE.json configs[1])"}.get(args.shape, args.shape),
+                         n_docs, n_feat, q_total, "~120 log-normal" if kind == "mslr" else "5..15", world, n_leaves),
+            "docs_total": n_docs, "docs_rank0": int(X.shape[0]), "features": n_feat, "queries_total": q_total, "leaves": n_leaves,
             "ndcg10_train_after_%d_rounds" % total_rounds: ndcg_t,
             "init_seconds": round(t_init, 3), "datagen_seconds": round(t_gen, 3),
         },
@@ -139,12 +142,12 @@ def main():
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": per_launch_ms, "launches": int(n_root),
-            "note": "algorithmic bytes = N*(F*2 B bin ids + 8 B fixed-point lambda); HIP events on the library stream",
+            "note": "algorithmic bytes = N_local*(F*2 B bin ids + 8 B fixed-point lambda); HIP events on the library stream",
         }
         out["kernel_ms_per_round"] = {"hist_root": ms_root / args.steps, "hist_node": ms_node / args.steps,
                                       "lambda": ms_lam / args.steps}
 
-    if args.cpu_rounds > 0:
+    if args.cpu_rounds > 0 and world == 1:
         import oracle_ffi as O
         threads = args.cpu_threads or (os.cpu_count() or 1)
         o = O.Oracle(X, lab, qoff, n_trees=args.cpu_rounds, n_leaves=n_leaves, n_threads=threads)

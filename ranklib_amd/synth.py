@@ -124,3 +124,25 @@ SHAPES = {
     "c1ns": (1_200_000, 136, "ns", 1000, 31),
     "c2": (3_770_000, 136, "mslr", 1000, 31),
 }
+
+
+def make_shard(n_docs, n_features=136, kind="mslr", rank=0, world=1, seed_offset=0, cut_sample=262144):
+    """rank's contiguous shard of the SAME global data set for any `world` (strong scaling): only the shard's
+    feature rows are generated.  Label cuts come from a fixed prefix sample so every rank labels identically."""
+    from . import dist as D
+    qoff = query_sizes(n_docs, kind, SEED_QSIZE + seed_offset)
+    qb, qe = D.partition_queries(qoff, world)[rank]
+    d0, d1 = int(qoff[qb]), int(qoff[qe])
+    ns = min(cut_sample, n_docs)
+    Xs = features(ns, n_features, 0, SEED_DATA + seed_offset)
+    _, cuts = labels_from(Xs, 0, SEED_LABEL + seed_offset)
+    if d0 == 0 and d1 <= ns:
+        X = Xs[:d1]
+    elif d0 == 0:
+        X = np.empty((d1, n_features), dtype=np.float32)
+        X[:ns] = Xs
+        features(d1 - ns, n_features, ns, SEED_DATA + seed_offset, out=X[ns:])
+    else:
+        X = features(d1 - d0, n_features, d0, SEED_DATA + seed_offset)
+    lab, _ = labels_from(X, d0, SEED_LABEL + seed_offset, cuts=cuts)
+    return X, lab, (qoff[qb:qe + 1] - qoff[qb]).astype(np.int32), int(len(qoff) - 1)
