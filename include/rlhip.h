@@ -189,8 +189,9 @@ enum {
     RL_ARR_QUANT = 10,       /* int64[n_docs]               fixed-point lambdas of the last round */
     RL_ARR_ROOT_SUM_FIXED = 11, /* int64[2*n_features*stride] (hi,lo) 128-bit cumulative fixed-point sums */
     RL_ARR_NDCG_PER_QUERY = 12, /* double[n_queries] of the last round */
-    RL_ARR_CHAIN_STATS = 13     /* int32[4]: leaf float chains evaluated, of which needed the serial fallback;
-                                   metric chains evaluated, of which needed the serial fallback */
+    RL_ARR_CHAIN_STATS = 13,    /* int32[6]: leaf float chains {evaluated, candidate-window misses repaired, finished
+                                   by the serial kernel}; the same three for the per-round metric chain */
+    RL_ARR_CHAIN_MISS = 14      /* int32[2*(2*n_leaves)]: per (value array, leaf slot) window misses of the last round */
 };
 int rl_bin_stride(const rl_trainer *t, int32_t *stride);
 int rl_quant_exponent(const rl_trainer *t, int32_t *e);   /* q = rint(lambda * 2^e) in the last round */

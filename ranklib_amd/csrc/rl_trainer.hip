@@ -227,10 +227,15 @@ static int alloc_chain(rl_trainer *t, ChainBufs &b, int maxseg, int A, int64_t n
     RL_HIP(t->pool.alloc(&b.tile_tot, (size_t)A * b.cap_tiles)); RL_HIP(t->pool.alloc(&b.tile_base, (size_t)A * b.cap_tiles));
     RL_HIP(t->pool.alloc(&b.bnd, (size_t)A * b.cap_tiles));
     RL_HIP(t->pool.alloc(&b.cbase, (size_t)A * b.cap_chunks)); RL_HIP(t->pool.alloc(&b.drift, (size_t)A * b.cap_chunks));
-    RL_HIP(t->pool.alloc(&b.gkey, (size_t)A * b.cap_chunks)); RL_HIP(t->pool.alloc(&b.R, (size_t)A * b.cap_chunks * kChainW));
+    RL_HIP(t->pool.alloc(&b.gkey, (size_t)A * b.cap_chunks)); RL_HIP(t->pool.alloc(&b.gkey2, (size_t)A * b.cap_chunks));
+    RL_HIP(t->pool.alloc(&b.R, (size_t)A * b.cap_chunks * kChainW));
     RL_HIP(t->pool.alloc(&b.result, (size_t)A * maxseg)); RL_HIP(t->pool.alloc(&b.miss, (size_t)A * maxseg));
-    RL_HIP(t->pool.alloc(&b.stats, (size_t)2));
-    RL_HIP(hipMemset(b.stats, 0, 2 * sizeof(int32_t)));
+    RL_HIP(t->pool.alloc(&b.st_status, (size_t)A * maxseg)); RL_HIP(t->pool.alloc(&b.st_chunk, (size_t)A * maxseg));
+    RL_HIP(t->pool.alloc(&b.st_key, (size_t)A * maxseg)); RL_HIP(t->pool.alloc(&b.st_delta, (size_t)A * maxseg));
+    RL_HIP(hipMemset(b.st_status, 0, (size_t)A * maxseg * sizeof(int32_t)));
+    RL_HIP(hipMemset(b.miss, 0, (size_t)A * maxseg * sizeof(int32_t)));
+    RL_HIP(t->pool.alloc(&b.stats, (size_t)4));
+    RL_HIP(hipMemset(b.stats, 0, 4 * sizeof(int32_t)));
     RL_HIP(hipMemset(b.plan, 0, sizeof(ChainPlan)));
     return RL_OK;
 }
@@ -245,9 +250,16 @@ static void enqueue_chain(rl_trainer *t, const ChainBufs &b, const ChainSource &
     hipLaunchKernelGGL(k_chain_bounds, dim3(tb, b.A), dim3(kThreads), 0, s, b);
     hipLaunchKernelGGL(k_chain_pass1, dim3((unsigned)((b.cap_chunks + kThreads - 1) / kThreads), b.A), dim3(kThreads), 0, s, b);
     hipLaunchKernelGGL(k_chain_guess, dim3(b.A), dim3(kThreads), 0, s, b);
-    hipLaunchKernelGGL(k_chain_tables, dim3((unsigned)((b.cap_chunks * kChainW + kThreads - 1) / kThreads), b.A), dim3(kThreads), 0, s, b);
+    const dim3 tgrid((unsigned)((b.cap_chunks * kChainW + kThreads - 1) / kThreads), b.A);
+    const dim3 cgrid((unsigned)((b.cap_chunks + kThreads - 1) / kThreads), b.A);
+    hipLaunchKernelGGL(k_chain_tables<false>, tgrid, dim3(kThreads), 0, s, b);
     const size_t lds = (size_t)(b.cap_chunks / kChainGroup + 2) * kChainW * sizeof(uint32_t);
     hipLaunchKernelGGL(k_chain_stitch, dim3(b.maxseg, b.A), dim3(kThreads), lds, s, b);
+    for (int rep = 0; rep < kChainRepairs; rep++) {      // near-empty launches unless a window was missed
+        hipLaunchKernelGGL(k_chain_tables<true>, tgrid, dim3(kThreads), 0, s, b);
+        hipLaunchKernelGGL(k_chain_commit, cgrid, dim3(kThreads), 0, s, b);
+        hipLaunchKernelGGL(k_chain_stitch, dim3(b.maxseg, b.A), dim3(kThreads), lds, s, b);
+    }
     hipLaunchKernelGGL(k_chain_fallback, dim3(b.maxseg, b.A), dim3(64), 0, s, b);
 }
 
@@ -1059,9 +1071,16 @@ int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes)
     case RL_ARR_QUANT: src = c.q; bytes = (size_t)c.N * 8; break;
     case RL_ARR_NDCG_PER_QUERY: src = c.ndcg_q; bytes = (size_t)c.Q * 8; break;
     case RL_ARR_CHAIN_STATS: {
-        if (cap_bytes < 16) return fail(RL_ERR_INVALID, "output buffer too small");
-        RL_HIP(hipMemcpy(out, t->leaf_chain.stats, 8, hipMemcpyDeviceToHost));
-        RL_HIP(hipMemcpy((char *)out + 8, t->metric_chain.stats, 8, hipMemcpyDeviceToHost));
+        if (cap_bytes < 24) return fail(RL_ERR_INVALID, "output buffer too small");
+        RL_HIP(hipMemcpy(out, (t->dist ? t->gchain : t->leaf_chain).stats, 12, hipMemcpyDeviceToHost));
+        RL_HIP(hipMemcpy((char *)out + 12, t->metric_chain.stats, 12, hipMemcpyDeviceToHost));
+        return RL_OK;
+    }
+    case RL_ARR_CHAIN_MISS: {
+        const ChainBufs &b = t->dist ? t->gchain : t->leaf_chain;
+        bytes = (size_t)2 * b.maxseg * 4;
+        if ((int64_t)bytes > cap_bytes) return fail(RL_ERR_INVALID, "output buffer too small");
+        RL_HIP(hipMemcpy(out, b.miss, bytes, hipMemcpyDeviceToHost));
         return RL_OK;
     }
     case RL_ARR_BINS: {
