@@ -12,8 +12,9 @@ namespace rl {
 
 constexpr int kThreads = 256;        // 4 wavefronts of 64
 constexpr int kWave = 64;
-constexpr int kLog2Chunk = 13;       // docs accumulated into one LDS histogram copy before it is flushed
-constexpr int kChunk = 1 << kLog2Chunk;
+constexpr int kLog2Chunk = 14;       // max docs accumulated into one int64 LDS accumulator (fixes the fixed-point exponent)
+constexpr int kChunk = 1 << kLog2Chunk;   // chunk of the root histogram
+constexpr int kNodeChunk = 8192;     // largest chunk of a child-node histogram
 constexpr int kMinChunk = 2048;      // smallest chunk a (small) node is cut into
 constexpr int kHistFG = 8;           // features per histogram block
 constexpr int kPartTile = 2048;      // docs per partition tile (256 threads x 8)

@@ -162,14 +162,20 @@ static int upload_query_side(rl_trainer *t, DataSet &d, const std::vector<double
     RL_HIP(t->pool.alloc(&d.d_ndcg, (size_t)d.Q));
     std::vector<int32_t> small, big;
     for (int32_t q = 0; q < d.Q; q++) ((d.qoff[q + 1] - d.qoff[q]) <= kLambdaWaveCap ? small : big).push_back(q);
+    // longest first: a block's work grows with n (n^2 for the rank), so late long lists would leave a tail
+    auto by_len = [&](int32_t a, int32_t b) { return (d.qoff[a + 1] - d.qoff[a]) > (d.qoff[b + 1] - d.qoff[b]); };
+    std::stable_sort(small.begin(), small.end(), by_len);
+    std::stable_sort(big.begin(), big.end(), by_len);
     d.n_small = (int32_t)small.size(); d.n_big = (int32_t)big.size();
-    d.all_small = big.empty();
+    d.all_small = false;      // the lists are permutations now: always index through them
     RL_HIP(t->pool.alloc(&d.d_qsmall, small.size()));
     RL_HIP(t->pool.alloc(&d.d_qbig, big.size()));
     if (!small.empty()) RL_HIP(hipMemcpy(d.d_qsmall, small.data(), small.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (!big.empty()) RL_HIP(hipMemcpy(d.d_qbig, big.data(), big.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     std::vector<int32_t> q128, qlong;
     for (int32_t q = 0; q < d.Q; q++) ((d.qoff[q + 1] - d.qoff[q]) <= kLambdaFusedSmall ? q128 : qlong).push_back(q);
+    std::stable_sort(q128.begin(), q128.end(), by_len);
+    std::stable_sort(qlong.begin(), qlong.end(), by_len);
     d.n_q128 = (int32_t)q128.size(); d.n_qlong = (int32_t)qlong.size();
     RL_HIP(t->pool.alloc(&d.d_q128, q128.size())); RL_HIP(t->pool.alloc(&d.d_qlong, qlong.size()));
     if (!q128.empty()) RL_HIP(hipMemcpy(d.d_q128, q128.data(), q128.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -248,7 +254,7 @@ static void enqueue_chain(rl_trainer *t, const ChainBufs &b, const ChainSource &
     hipLaunchKernelGGL(k_chain_prefix, dim3(tb, b.A), dim3(kThreads), 0, s, b, src);
     hipLaunchKernelGGL(k_chain_scan_tiles, dim3(b.A), dim3(kThreads), 0, s, b);
     hipLaunchKernelGGL(k_chain_bounds, dim3(tb, b.A), dim3(kThreads), 0, s, b);
-    hipLaunchKernelGGL(k_chain_pass1, dim3((unsigned)((b.cap_chunks + kThreads - 1) / kThreads), b.A), dim3(kThreads), 0, s, b);
+    hipLaunchKernelGGL(k_chain_pass1, dim3((unsigned)((b.cap_chunks * 16 + kThreads - 1) / kThreads), b.A), dim3(kThreads), 0, s, b);
     hipLaunchKernelGGL(k_chain_guess, dim3(b.A), dim3(kThreads), 0, s, b);
     const dim3 tgrid((unsigned)((b.cap_chunks * kChainW + kThreads - 1) / kThreads), b.A);
     const dim3 cgrid((unsigned)((b.cap_chunks + kThreads - 1) / kThreads), b.A);
@@ -316,8 +322,8 @@ static int enqueue_round(rl_trainer *t)
         LamArgs g{t->tr.d_ss, t->tr.d_sl, t->tr.d_srel, t->tr.d_sidx, c.qoff, t->tr.d_docq, m == 0 ? c.ideal0 : c.ideal1, c.disc,
                   t->d_T, c.lambda, c.weight, &c.st->maxabs_bits, c.N, c.k, c.k};
         if (c.k <= kLambdaFusedMaxK) {
-            const size_t l128 = (size_t)c.k * 128 * 16 + (size_t)c.k * 16 + 128 * 4;
-            const size_t l256 = (size_t)c.k * 256 * 16 + (size_t)c.k * 16 + 256 * 4;
+            const size_t l128 = (size_t)c.k * 128 * 16 + (size_t)c.k * 24 + 128 * 4;
+            const size_t l256 = (size_t)c.k * 256 * 16 + (size_t)c.k * 24 + 256 * 4;
             if (t->tr.n_q128 > 0) hipLaunchKernelGGL(k_lambda_fused<128>, dim3(t->tr.n_q128), dim3(128), l128, s, g, (const int *)t->tr.d_q128, t->tr.n_q128);
             if (t->tr.n_qlong > 0) hipLaunchKernelGGL(k_lambda_fused<256>, dim3(t->tr.n_qlong), dim3(256), l256, s, g, (const int *)t->tr.d_qlong, t->tr.n_qlong);
         } else {
@@ -330,7 +336,7 @@ static int enqueue_round(rl_trainer *t)
     hipLaunchKernelGGL(k_quantize, dim3(std::min(2048, (c.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, c);
     const size_t hist_lds = (size_t)c.FG * c.TS * 12;
     const size_t fin_lds = (size_t)c.TS * 20;
-    const int rootCs = std::min(kChunk, std::max(kMinChunk, (((c.N + 63) / 64 + 255) & ~255)));   // == chunk_docs(N)
+    const int rootCs = std::min(kChunk, std::max(kMinChunk, (((c.N + 63) / 64 + 255) & ~255)));   // == chunk_docs<true>(N)
     const int rootChunks = (c.N + rootCs - 1) / rootCs;
     {   // K2 root histogram
         ScopedTiming tm(t, RL_KERNEL_HIST_ROOT, (double)c.N * ((double)c.F * 2.0 + 8.0));
@@ -681,7 +687,7 @@ int rl_init(rl_trainer *t)
     RL_HIP(t->pool.alloc(&d_bins, (size_t)F * Npad));
     RL_HIP(hipMemsetAsync(d_bins, 0, (size_t)F * Npad * sizeof(uint16_t), s));
     c.bins = d_bins;
-    c.maxChunks = std::max((N + kChunk - 1) / kChunk, 64) + 1;      // see chunk_docs()
+    c.maxChunks = std::max((N + kNodeChunk - 1) / kNodeChunk, 64) + 1;      // see chunk_docs()
     c.nTiles = (N + kPartTile - 1) / kPartTile;
     RL_HIP(t->pool.alloc(&c.cum_hi, (size_t)c.MAXN * F * TS));
     RL_HIP(t->pool.alloc(&c.cum_lo, (size_t)c.MAXN * F * TS));
