@@ -15,8 +15,9 @@ constexpr int kWave = 64;
 constexpr int kLog2Chunk = 14;       // max docs accumulated into one int64 LDS accumulator (fixes the fixed-point exponent)
 constexpr int kChunk = 1 << kLog2Chunk;   // chunk of the root histogram
 constexpr int kNodeChunk = 8192;     // largest chunk of a child-node histogram
-constexpr int kMinChunk = 2048;      // smallest chunk a (small) node is cut into
-constexpr int kHistFG = 8;           // features per histogram block
+constexpr int kMinChunk = 512;       // smallest chunk a (small) node is cut into
+constexpr int kHistDocs = 2;         // samples per thread and iteration of the histogram kernel
+constexpr int kHistFG = 16;          // features per group of the histogram layout gbins[group][doc][kHistFG]
 constexpr int kPartTile = 2048;      // docs per partition tile (256 threads x 8)
 constexpr int kMaxBins = 4096;       // bin stride limit (thresholds per feature incl. MAX_VALUE)
 constexpr int kHistLdsBytes = 64 * 1024;
@@ -63,7 +64,9 @@ struct Ctx {
     int32_t rank, n_ranks;
     long long *dist_buf;     // [F*TS*3 + 4] int64 limbs of the histogram being all-reduced (multi-GPU only)
     // static per data set
-    const uint16_t *bins;   // [F][Npad]
+    const uint16_t *bins;   // [F][Npad]  feature-major: single-column scans (partition)
+    const uint16_t *gbins;  // [numFG][Npad][kHistFG]  group-major: one 32-byte row per document and group (histograms)
+    int32_t sub;            // features of a group handled per histogram block (kHistFG unless the threshold table is huge)
     const float *thr;       // [F][TS]
     const int32_t *nthr;    // [F]
     const int32_t *feature_ids;
@@ -75,6 +78,7 @@ struct Ctx {
     double *scores, *lambda, *weight, *ndcg_q;
     long long *q, *r;
     int32_t *idx[2];
+    long long *ql[2];        // fixed-point lambda in sample-list order (travels with idx through the partitions)
     NodeRec *nodes;
     TreeState *st;
     int32_t *queue;

@@ -297,6 +297,19 @@ static int launch_rank(rl_trainer *t, DataSet &d, const double *scores, double *
     return RL_OK;
 }
 
+template <bool ROOT>
+static void launch_hist(const Ctx &c, int gx, int gy, size_t lds, hipStream_t s)
+{
+    const dim3 g(gx, gy), b(kThreads);
+    switch (c.sub) {
+    case 16: hipLaunchKernelGGL((k_hist<ROOT, 16>), g, b, lds, s, c); break;
+    case 8: hipLaunchKernelGGL((k_hist<ROOT, 8>), g, b, lds, s, c); break;
+    case 4: hipLaunchKernelGGL((k_hist<ROOT, 4>), g, b, lds, s, c); break;
+    case 2: hipLaunchKernelGGL((k_hist<ROOT, 2>), g, b, lds, s, c); break;
+    default: hipLaunchKernelGGL((k_hist<ROOT, 1>), g, b, lds, s, c); break;
+    }
+}
+
 // multi-GPU: per-query values of all ranks in global query order (ranks hold ascending contiguous query ranges)
 static int gather_queries(rl_trainer *t, const double *local, const double **out)
 {
@@ -334,14 +347,14 @@ static int enqueue_round(rl_trainer *t)
     }
     if (t->dist) { int rcd = t->dist->allreduce(&c.st->maxabs_bits, 1, DT_U64, OP_MAX, s); if (rcd) return rcd; }
     hipLaunchKernelGGL(k_quantize, dim3(std::min(2048, (c.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, c);
-    const size_t hist_lds = (size_t)c.FG * c.TS * 12;
+    const size_t hist_lds = (size_t)c.sub * c.TS * 8 + (size_t)c.sub * ((c.TS + 1) / 2) * 4;
+    const int hist_gx = c.numFG * (kHistFG / c.sub);
     const size_t fin_lds = (size_t)c.TS * 20;
     const int rootCs = std::min(kChunk, std::max(kMinChunk, (((c.N + 63) / 64 + 255) & ~255)));   // == chunk_docs<true>(N)
     const int rootChunks = (c.N + rootCs - 1) / rootCs;
     {   // K2 root histogram
         ScopedTiming tm(t, RL_KERNEL_HIST_ROOT, (double)c.N * ((double)c.F * 2.0 + 8.0));
-        if (c.FG == kHistFG) hipLaunchKernelGGL((k_hist<true, kHistFG>), dim3(c.numFG, rootChunks), dim3(kThreads), hist_lds, s, c);
-        else hipLaunchKernelGGL((k_hist<true, 1>), dim3(c.numFG, rootChunks), dim3(kThreads), hist_lds, s, c);
+        launch_hist<true>(c, hist_gx, rootChunks, hist_lds, s);
     }
     if (t->dist) {
         hipLaunchKernelGGL(k_hist_reduce, dim3(c.F), dim3(kThreads), 0, s, c, 1);
@@ -356,8 +369,7 @@ static int enqueue_round(rl_trainer *t)
         hipLaunchKernelGGL(k_part_scatter, dim3(c.nTiles), dim3(kThreads), 0, s, c);
         {
             ScopedTiming tm(t, RL_KERNEL_HIST_NODE, 0.0);
-            if (c.FG == kHistFG) hipLaunchKernelGGL((k_hist<false, kHistFG>), dim3(c.numFG, c.maxChunks), dim3(kThreads), hist_lds, s, c);
-            else hipLaunchKernelGGL((k_hist<false, 1>), dim3(c.numFG, c.maxChunks), dim3(kThreads), hist_lds, s, c);
+            launch_hist<false>(c, hist_gx, c.maxChunks, hist_lds, s);
         }
         if (t->dist) {
             hipLaunchKernelGGL(k_hist_reduce, dim3(c.F), dim3(kThreads), 0, s, c, 0);
@@ -540,8 +552,14 @@ int rl_create(const rl_params *p, rl_trainer **out)
     memset(&t->ctx, 0, sizeof(t->ctx));
     memset(&t->ens, 0, sizeof(t->ens));
     RL_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
-    RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, kHistFG>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
-    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, kHistFG>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
@@ -678,15 +696,19 @@ int rl_init(rl_trainer *t)
     RL_HIP(hipMemsetAsync(d_thr, 0, (size_t)F * TS * sizeof(float), s));
     RL_HIP(hipMemcpy2DAsync(d_thr, TS * sizeof(float), thr0, TS0 * sizeof(float), TS * sizeof(float), F, hipMemcpyDeviceToDevice, s));
     c.thr = d_thr; c.nthr = d_nthr;
-    if ((size_t)TS * 12 > (size_t)kHistLdsBytes) return fail(RL_ERR_UNSUPPORTED, "too many threshold candidates for the LDS histogram");
-    // features per histogram block: kHistFG when the LDS budget allows, else 1 (very wide threshold tables)
-    c.FG = ((size_t)kHistFG * TS * 12 <= (size_t)kHistLdsBytes) ? kHistFG : 1;
-    c.numFG = (F + c.FG - 1) / c.FG;
+    if ((size_t)TS * 10 > (size_t)kHistLdsBytes) return fail(RL_ERR_UNSUPPORTED, "too many threshold candidates for the LDS histogram");
+    // features of a 16-feature group handled by one histogram block: all 16 when the LDS budget allows
+    c.FG = kHistFG;
+    c.numFG = (F + kHistFG - 1) / kHistFG;
+    c.sub = 16;
+    while (c.sub > 1 && (size_t)c.sub * TS * 8 + (size_t)c.sub * ((TS + 1) / 2) * 4 > (size_t)kHistLdsBytes) c.sub >>= 1;
 
-    uint16_t *d_bins = nullptr;
+    uint16_t *d_bins = nullptr, *d_gbins = nullptr;
     RL_HIP(t->pool.alloc(&d_bins, (size_t)F * Npad));
     RL_HIP(hipMemsetAsync(d_bins, 0, (size_t)F * Npad * sizeof(uint16_t), s));
-    c.bins = d_bins;
+    RL_HIP(t->pool.alloc(&d_gbins, (size_t)c.numFG * Npad * kHistFG));
+    RL_HIP(hipMemsetAsync(d_gbins, 0, (size_t)c.numFG * Npad * kHistFG * sizeof(uint16_t), s));
+    c.bins = d_bins; c.gbins = d_gbins;
     c.maxChunks = std::max((N + kNodeChunk - 1) / kNodeChunk, 64) + 1;      // see chunk_docs()
     c.nTiles = (N + kPartTile - 1) / kPartTile;
     RL_HIP(t->pool.alloc(&c.cum_hi, (size_t)c.MAXN * F * TS));
@@ -694,7 +716,7 @@ int rl_init(rl_trainer *t)
     RL_HIP(t->pool.alloc(&c.cum_cnt, (size_t)c.MAXN * F * TS));
     RL_HIP(hipMemsetAsync(c.cum_cnt, 0, (size_t)F * TS * sizeof(int32_t), s));
     hipLaunchKernelGGL(k_binning, dim3(F, slices), dim3(kThreads), (size_t)TS * 8, s, (const float *)Xt, N, Npad, TS, (const float *)d_thr,
-                       (const int32_t *)d_nthr, d_bins, c.cum_cnt);
+                       (const int32_t *)d_nthr, d_bins, d_gbins, c.cum_cnt);
     if (t->dist) { int rcd = t->dist->allreduce(c.cum_cnt, (size_t)F * TS, DT_I32, OP_SUM, s); if (rcd) return rcd; }
     hipLaunchKernelGGL(k_cumulate_counts, dim3(F), dim3(64), 0, s, TS, (const int32_t *)d_nthr, c.cum_cnt);
     RL_HIP(hipGetLastError());
@@ -744,6 +766,7 @@ int rl_init(rl_trainer *t)
     RL_HIP(t->pool.alloc(&c.lambda, (size_t)N)); RL_HIP(t->pool.alloc(&c.weight, (size_t)N));
     RL_HIP(t->pool.alloc(&c.q, (size_t)N)); RL_HIP(t->pool.alloc(&c.r, (size_t)N));
     RL_HIP(t->pool.alloc(&c.idx[0], (size_t)N)); RL_HIP(t->pool.alloc(&c.idx[1], (size_t)N));
+    RL_HIP(t->pool.alloc(&c.ql[0], (size_t)N)); RL_HIP(t->pool.alloc(&c.ql[1], (size_t)N));
     RL_HIP(t->pool.alloc(&c.nodes, (size_t)c.MAXN + 2)); RL_HIP(t->pool.alloc(&c.st, (size_t)1));
     RL_HIP(hipMemset(c.st, 0, sizeof(TreeState)));
     RL_HIP(hipMemset(c.nodes, 0, ((size_t)c.MAXN + 2) * sizeof(NodeRec)));
