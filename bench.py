@@ -138,7 +138,7 @@ def main():
         alg_bytes = bytes_root / n_root
         achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
         out["roofline"] = {
-            "kernel": "rl::k_hist<true> (root histogram, FeatureHistogram.update)",
+            "kernel": "rl::k_hist<true,16> (root histogram, FeatureHistogram.update)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": per_launch_ms, "launches": int(n_root),

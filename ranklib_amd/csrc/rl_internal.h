@@ -67,6 +67,7 @@ struct Ctx {
     const uint16_t *bins;   // [F][Npad]  feature-major: single-column scans (partition)
     const uint16_t *gbins;  // [numFG][Npad][kHistFG]  group-major: one 32-byte row per document and group (histograms)
     int32_t sub;            // features of a group handled per histogram block (kHistFG unless the threshold table is huge)
+    const int32_t *mode;    // [F] most populated bin of every feature: never accumulated, rebuilt as total - others
     const float *thr;       // [F][TS]
     const int32_t *nthr;    // [F]
     const int32_t *feature_ids;
@@ -84,6 +85,7 @@ struct Ctx {
     int32_t *queue;
     long long *cum_hi; unsigned long long *cum_lo; int32_t *cum_cnt;   // [MAXN][F][TS] cumulative
     long long *part_sum; int32_t *part_cnt;                            // [maxChunks][F][TS]
+    long long *part_tot;                                               // [maxChunks] sum of q over the chunk's samples
     double *fb_S; int32_t *fb_t;                                       // [2][F]
     int32_t *tile_cnt;                                                 // [nTiles]
     int32_t *leaf_node, *leaf_start;                                   // [MAXN], [MAXN+1]

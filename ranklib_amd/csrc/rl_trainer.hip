@@ -357,7 +357,7 @@ static int enqueue_round(rl_trainer *t)
         launch_hist<true>(c, hist_gx, rootChunks, hist_lds, s);
     }
     if (t->dist) {
-        hipLaunchKernelGGL(k_hist_reduce, dim3(c.F), dim3(kThreads), 0, s, c, 1);
+        hipLaunchKernelGGL(k_hist_reduce, dim3(c.F), dim3(kThreads), fin_lds, s, c, 1);
         int rcd = t->dist->allreduce(c.dist_buf, (size_t)c.F * c.TS * 3 + 4, DT_I64, OP_SUM, s);
         if (rcd) return rcd;
         hipLaunchKernelGGL((k_hist_finish<true, true>), dim3(c.F), dim3(kThreads), fin_lds, s, c);
@@ -372,7 +372,7 @@ static int enqueue_round(rl_trainer *t)
             launch_hist<false>(c, hist_gx, c.maxChunks, hist_lds, s);
         }
         if (t->dist) {
-            hipLaunchKernelGGL(k_hist_reduce, dim3(c.F), dim3(kThreads), 0, s, c, 0);
+            hipLaunchKernelGGL(k_hist_reduce, dim3(c.F), dim3(kThreads), fin_lds, s, c, 0);
             int rcd = t->dist->allreduce(c.dist_buf, (size_t)c.F * c.TS * 3 + 4, DT_I64, OP_SUM, s);
             if (rcd) return rcd;
             hipLaunchKernelGGL((k_hist_finish<false, true>), dim3(c.F), dim3(kThreads), fin_lds, s, c);
@@ -562,6 +562,7 @@ int rl_create(const rl_params *p, rl_trainer **out)
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
@@ -718,7 +719,10 @@ int rl_init(rl_trainer *t)
     hipLaunchKernelGGL(k_binning, dim3(F, slices), dim3(kThreads), (size_t)TS * 8, s, (const float *)Xt, N, Npad, TS, (const float *)d_thr,
                        (const int32_t *)d_nthr, d_bins, d_gbins, c.cum_cnt);
     if (t->dist) { int rcd = t->dist->allreduce(c.cum_cnt, (size_t)F * TS, DT_I32, OP_SUM, s); if (rcd) return rcd; }
-    hipLaunchKernelGGL(k_cumulate_counts, dim3(F), dim3(64), 0, s, TS, (const int32_t *)d_nthr, c.cum_cnt);
+    int32_t *d_mode = nullptr;
+    RL_HIP(t->pool.alloc(&d_mode, (size_t)F));
+    c.mode = d_mode;
+    hipLaunchKernelGGL(k_cumulate_counts, dim3(F), dim3(64), 0, s, TS, (const int32_t *)d_nthr, c.cum_cnt, d_mode);
     RL_HIP(hipGetLastError());
     RL_HIP(hipStreamSynchronize(s));
     t->pool.release(Xt); t->pool.release(thr0); t->pool.release(fs.set);
@@ -772,6 +776,7 @@ int rl_init(rl_trainer *t)
     RL_HIP(hipMemset(c.nodes, 0, ((size_t)c.MAXN + 2) * sizeof(NodeRec)));
     RL_HIP(t->pool.alloc(&c.queue, (size_t)c.MAXN + 2));
     RL_HIP(t->pool.alloc(&c.part_sum, (size_t)c.maxChunks * F * TS)); RL_HIP(t->pool.alloc(&c.part_cnt, (size_t)c.maxChunks * F * TS));
+    RL_HIP(t->pool.alloc(&c.part_tot, (size_t)std::max(c.maxChunks, (N + kMinChunk - 1) / kMinChunk) + 1));
     RL_HIP(t->pool.alloc(&c.fb_S, (size_t)2 * F)); RL_HIP(t->pool.alloc(&c.fb_t, (size_t)2 * F));
     RL_HIP(t->pool.alloc(&c.tile_cnt, (size_t)c.nTiles));
     RL_HIP(t->pool.alloc(&c.leaf_node, (size_t)c.MAXN + 1)); RL_HIP(t->pool.alloc(&c.leaf_start, (size_t)c.MAXN + 2));
