@@ -362,7 +362,8 @@ static int enqueue_round(rl_trainer *t)
         if (rcd) return rcd;
         hipLaunchKernelGGL((k_hist_finish<true, true>), dim3(c.F), dim3(kThreads), fin_lds, s, c);
     } else hipLaunchKernelGGL((k_hist_finish<true, false>), dim3(c.F), dim3(kThreads), fin_lds, s, c);
-    hipLaunchKernelGGL(k_select, dim3(1), dim3(64), 0, s, c, 1);
+    const size_t sel_lds = ((sizeof(SelShared) + 15) & ~(size_t)15) + (size_t)(c.MAXN + 2) * 12;
+    hipLaunchKernelGGL(k_select, dim3(1), dim3(64), sel_lds, s, c, 1);
     const int steps = c.L - 1;
     for (int it = 0; it < steps; it++) {
         hipLaunchKernelGGL(k_part_count, dim3(c.nTiles), dim3(kThreads), 0, s, c);
@@ -377,7 +378,7 @@ static int enqueue_round(rl_trainer *t)
             if (rcd) return rcd;
             hipLaunchKernelGGL((k_hist_finish<false, true>), dim3(c.F), dim3(kThreads), fin_lds, s, c);
         } else hipLaunchKernelGGL((k_hist_finish<false, false>), dim3(c.F), dim3(kThreads), fin_lds, s, c);
-        hipLaunchKernelGGL(k_select, dim3(1), dim3(64), 0, s, c, 0);
+        hipLaunchKernelGGL(k_select, dim3(1), dim3(64), sel_lds, s, c, 0);
     }
     hipLaunchKernelGGL(k_leaf_table, dim3(1), dim3(64), 0, s, c, t->leaf_chain, t->d_seg_buf);
     if (t->p.flags & RL_FLAG_SERIAL_CHAIN) {
