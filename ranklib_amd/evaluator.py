@@ -1,0 +1,136 @@
+"""Command line of the `-ranker 6` path: mirrors the flags of eval/Evaluator.java that reach LambdaMART
+(:230-377) and the train / test / load / score / rank flows (:669-708, :1076-1094, :1168-1194).
+
+    python -m ranklib_amd.evaluator -train f -ranker 6 -metric2t NDCG@10 -tree 1000 -leaf 31 -save model.txt
+    python -m ranklib_amd.evaluator -load model.txt -rank f -score out.txt
+"""
+import logging
+import sys
+
+from ._native import RankLibError
+from .features import FeatureManager
+from .learning import DataPoint, LambdaMART, RankerFactory, RankerTrainer, RankerType, java_round, stable_desc_order
+from .metric import MetricScorerFactory
+
+logger = logging.getLogger("ranklib_amd")
+
+
+class Evaluator:
+    def __init__(self, rType, trainMetric, testMetric):
+        self.type = rType
+        mf = MetricScorerFactory()
+        self.trainScorer = mf.createScorer(trainMetric)
+        self.testScorer = mf.createScorer(testMetric)
+        self.rFact = RankerFactory()
+
+    def evaluate(self, trainFile, validationFile=None, testFile=None, featureDefFile=None, modelFile=None):   # :669-708
+        train = FeatureManager.readInput(trainFile)
+        validation = FeatureManager.readInput(validationFile) if validationFile else None
+        test = FeatureManager.readInput(testFile) if testFile else None
+        features = FeatureManager.readFeature(featureDefFile) if featureDefFile else FeatureManager.getFeatureFromSampleVector(train)
+        trainer = RankerTrainer()
+        if validation is not None:
+            ranker = trainer.train(self.type, train, validation, features, self.trainScorer)
+        else:
+            ranker = trainer.train(self.type, train, features, self.trainScorer)
+        trainer.printTrainingTime()
+        if test is not None:
+            s = self.testScorer.score(ranker.rank(test))
+            logger.info("%s on test data: %s", self.testScorer.name(), java_round(s, 4))
+        if modelFile:
+            ranker.save(modelFile)
+            logger.info("Model saved to: %s", modelFile)
+        return ranker
+
+    def score(self, modelFile, testFile, outputFile):      # :1076-1094: qid \t index \t score
+        ranker = self.rFact.loadRankerFromFile(modelFile)
+        test = FeatureManager.readInput(testFile)
+        with open(outputFile, "w", encoding="utf-8") as out:
+            for rl in test:
+                for j, v in enumerate(ranker.evalList(rl)):
+                    out.write("%s\t%d\t%s\n" % (rl.getID(), j, repr(float(v))))
+
+    def rank(self, modelFile, testFile, indriFile):        # :1168-1194: qid Q0 docno rank score indri
+        ranker = self.rFact.loadRankerFromFile(modelFile)
+        test = FeatureManager.readInput(testFile)
+        with open(indriFile, "w", encoding="utf-8") as out:
+            for rl in test:
+                sc = ranker.evalList(rl)
+                for i, j in enumerate(stable_desc_order(sc)):
+                    docno = rl.get(int(j)).getDescription().replace("#", "").strip()
+                    out.write("%s Q0 %s %d %s indri\n" % (rl.getID(), docno, i + 1, repr(java_round(float(sc[int(j)]), 5))))
+
+    def test(self, modelFile, testFile):                   # evaluate a saved model
+        ranker = self.rFact.loadRankerFromFile(modelFile)
+        test = FeatureManager.readInput(testFile)
+        s = self.testScorer.score(ranker.rank(test))
+        logger.info("%s on test data: %s", self.testScorer.name(), java_round(s, 4))
+        return s
+
+
+def main(argv=None):
+    args = list(sys.argv[1:] if argv is None else argv)
+    logging.basicConfig(level=logging.INFO, format="%(message)s")
+    if not args:
+        print("Usage: -train <file> -ranker 6 [-metric2t NDCG@k] [-tree n] [-leaf n] [-shrinkage f] [-tc n] [-mls n] [-estop n] "
+              "[-validate f] [-test f] [-feature f] [-save model] | -load model [-test f] [-rank f -indri out] [-score out]")
+        return 0
+    trainFile = validationFile = testFile = featureDescriptionFile = savedModelFile = rankFile = indriRankingFile = scoreFile = modelFile = ""
+    rankerType = 4                                          # the reference's default is Coordinate Ascent (:83)
+    trainMetric, testMetric = "ERR@10", ""                  # the reference's default train metric (:84)
+    i = 0
+    while i < len(args):                                    # :230-372 (flags are matched case-insensitively)
+        a = args[i].lower()
+
+        def nxt():
+            nonlocal i
+            i += 1
+            if i >= len(args):
+                raise RankLibError("Missing value for " + args[i - 1])
+            return args[i]
+        if a == "-train": trainFile = nxt()
+        elif a == "-ranker": rankerType = int(nxt())
+        elif a == "-feature": featureDescriptionFile = nxt()
+        elif a == "-metric2t": trainMetric = nxt()          # also captures -metric2T, exactly like the reference (:237-240)
+        elif a == "-gmax": nxt()
+        elif a == "-validate": validationFile = nxt()
+        elif a == "-test": testFile = nxt()
+        elif a == "-save": modelFile = nxt()
+        elif a == "-load": savedModelFile = nxt()
+        elif a == "-rank": rankFile = nxt()
+        elif a == "-score": scoreFile = nxt()
+        elif a == "-indri": indriRankingFile = nxt()
+        elif a == "-missingzero": DataPoint.missingZero = True
+        elif a == "-sparse": pass                           # row storage only (:268-269)
+        elif a == "-tree": LambdaMART.nTrees = int(nxt())
+        elif a == "-leaf": LambdaMART.nTreeLeaves = int(nxt())
+        elif a == "-shrinkage": LambdaMART.learningRate = float(nxt())
+        elif a == "-tc": LambdaMART.nThreshold = int(nxt())
+        elif a == "-mls": LambdaMART.minLeafSupport = int(nxt())
+        elif a == "-estop": LambdaMART.nRoundToStopEarly = int(nxt())
+        elif a == "-thread": nxt()                          # CPU thread pool of the reference: irrelevant here
+        elif a == "-device": LambdaMART.device = int(nxt())
+        else:
+            raise RankLibError("Unknown command-line parameter: " + args[i])     # :369-371 (incl. the documented -silent)
+        i += 1
+    if not testMetric:
+        testMetric = trainMetric                            # :379-381
+    if trainFile and rankerType != 6:
+        raise RankLibError("rlhip builds -ranker 6 (LambdaMART) only")
+    if not trainFile and trainMetric == "ERR@10":
+        trainMetric = testMetric = "NDCG@10"                # load / rank / score flows do not need the train metric
+    e = Evaluator(RankerType.LAMBDAMART, trainMetric, testMetric)
+    if trainFile:
+        e.evaluate(trainFile, validationFile or None, testFile or None, featureDescriptionFile or None, modelFile or None)
+    elif savedModelFile:
+        if rankFile and indriRankingFile:
+            e.rank(savedModelFile, rankFile, indriRankingFile)
+        elif rankFile and scoreFile:
+            e.score(savedModelFile, rankFile, scoreFile)
+        elif testFile:
+            e.test(savedModelFile, testFile)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

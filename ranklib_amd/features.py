@@ -1,0 +1,63 @@
+"""LETOR input: mirrors features/FeatureManager.java (readInput :187-245, readFeature :267-292,
+getFeatureFromSampleVector :303-322) and utilities/FileUtils.smartReader (.gz by extension)."""
+import gzip
+import logging
+
+from ._native import RankLibError
+from .learning import DataPoint, RankList
+
+logger = logging.getLogger("ranklib_amd")
+
+
+def smart_reader(path):
+    return gzip.open(path, "rt", encoding="utf-8") if path.endswith(".gz") else open(path, "r", encoding="utf-8")
+
+
+class FeatureManager:
+    @staticmethod
+    def readInput(inputFile, mustHaveRelDoc=False, useSparseRepresentation=False):
+        samples = []
+        countEntries = 0
+        try:
+            with smart_reader(inputFile) as f:
+                lastID, hasRel, rl = "", False, []
+                for content in f:
+                    content = content.strip()
+                    if not content or content[0] == "#":
+                        continue
+                    qp = DataPoint(content)          # sparse only changes row storage in the reference
+                    if lastID and lastID != qp.getID():
+                        if not mustHaveRelDoc or hasRel:
+                            samples.append(RankList(rl))
+                        rl, hasRel = [], False
+                    if qp.getLabel() > 0:
+                        hasRel = True
+                    lastID = qp.getID()
+                    rl.append(qp)
+                    countEntries += 1
+                if rl and (not mustHaveRelDoc or hasRel):
+                    samples.append(RankList(rl))
+            logger.info("(%d ranked lists, %d entries read)", len(samples), countEntries)
+        except RankLibError:
+            raise
+        except Exception as ex:       # noqa: BLE001
+            raise RankLibError("Error in FeatureManager::readInput(): %s" % ex)
+        return samples
+
+    @staticmethod
+    def readFeature(featureDefFile):
+        fids = []
+        with smart_reader(featureDefFile) as f:
+            for content in f:
+                content = content.strip()
+                if not content or content[0] == "#":
+                    continue
+                fids.append(int(content.split("\t")[0].strip()))
+        return fids
+
+    @staticmethod
+    def getFeatureFromSampleVector(samples):
+        if not samples:
+            raise RankLibError("Error in FeatureManager::getFeatureFromSampleVector(): There are no training samples.")
+        fc = max(rl.getFeatureCount() for rl in samples)
+        return list(range(1, fc + 1))

@@ -1,0 +1,105 @@
+"""Host mirror of the RankLib surface.  The CPU tests cover parsing / flags / factories; the GPU test restates the
+reference's own LambdaMART test (test:eval/EvaluatorTest.java:186-195 -> :207-260): write writeRandomData's
+file, train through the command line, save, load, rank to an Indri run file, check the behavioural property."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from ranklib_amd import evaluator, features, learning, metric
+from ranklib_amd._native import RankLibError
+
+
+def write_random_data(path, seed=0):
+    # test:eval/EvaluatorTest.java:65-76: ONE query, 100 x (1 qid:x 1:1.0 2:+-1 # P<i>), 100 x (0 qid:x 1:0.9 2:+-1 # N<i>)
+    rnd = random.Random(seed)
+    with open(path, "w") as f:
+        for i in range(100):
+            w1 = 1 if rnd.random() < 0.5 else -1
+            w2 = 1 if rnd.random() < 0.5 else -1
+            f.write("1 qid:x 1:1.0 2:%d # P%d\n" % (w1, i))
+            f.write("0 qid:x 1:0.9 2:%d # N%d\n" % (w2, i))
+
+
+def test_letor_parsing_and_datapoint_rules(tmp_path):
+    p = tmp_path / "a.txt"
+    p.write_text("# comment\n2 qid:10 1:0.5 3:1e-3 # doc A\n0 qid:10 2:7\n\n1 qid:11 1:1 2:2 3:3 #x\n")
+    rls = features.FeatureManager.readInput(str(p))
+    assert [rl.size() for rl in rls] == [2, 1] and rls[0].getID() == "10"
+    dp = rls[0].get(0)
+    assert dp.getLabel() == 2.0 and dp.getDescription() == "# doc A"
+    assert dp.getFeatureValue(1) == np.float32(0.5) and dp.getFeatureValue(2) == 0 and dp.getFeatureValue(3) == np.float32(1e-3)
+    with pytest.raises(RankLibError):
+        rls[0].get(1).getFeatureValue(3)              # beyond the row's last feature (DenseDataPoint.java:22-27)
+    learning.DataPoint.missingZero = True
+    try:
+        assert rls[0].get(1).getFeatureValue(3) == 0
+    finally:
+        learning.DataPoint.missingZero = False
+    assert features.FeatureManager.getFeatureFromSampleVector(rls) == [1, 2, 3]
+    with pytest.raises(RankLibError):
+        learning.flatten(rls, [1, 3])                 # the reference dies the same way in init() without -missingZero
+    learning.DataPoint.missingZero = True
+    try:
+        X, lab, qoff, qkey = learning.flatten(rls, [1, 3])
+    finally:
+        learning.DataPoint.missingZero = False
+    assert X.tolist() == [[0.5, float(np.float32(1e-3))], [0.0, 0.0], [1.0, 3.0]]
+    assert list(qoff) == [0, 2, 3] and list(lab) == [2, 0, 1] and list(qkey) == [0, 1]
+    with pytest.raises(RankLibError):
+        learning.DataPoint("-1 qid:1 1:2")             # negative label (DataPoint.java:71-73)
+    with pytest.raises(RankLibError):
+        learning.DataPoint("1 qid:1 0:2")              # feature ids start at 1 (:80-82)
+
+
+def test_metric_factory_and_ndcg_scorer():
+    mf = metric.MetricScorerFactory()
+    s = mf.createScorer("ndcg@5")
+    assert s.name() == "NDCG@5" and s.getK() == 5
+    assert mf.createScorer("NDCG").getK() == 10
+    with pytest.raises(RankLibError):
+        mf.createScorer("MAP")
+    rl = learning.RankList([learning.DataPoint("%d qid:q 1:0" % l) for l in (2, 0, 1)])
+    d = [1.0, 1.0 / (np.log(3) / np.log(2)), 0.5]
+    assert mf.createScorer("NDCG@10").score(rl) == (3 * d[0] + 0 * d[1] + 1 * d[2]) / 3.6309297535714573
+
+
+def test_cli_flag_quirks():
+    with pytest.raises(RankLibError) as e:
+        evaluator.main(["-train", "x", "-silent"])      # documented but unparsed in the reference (Evaluator.java:122,369-371)
+    assert "Unknown command-line parameter" in str(e.value)
+    with pytest.raises(RankLibError):
+        evaluator.main(["-train", "x", "-ranker", "4"])
+    assert learning.LambdaMART.nTrees == 1000 and learning.LambdaMART.nTreeLeaves == 10 and learning.LambdaMART.nThreshold == 256
+    assert learning.java_round(0.123449, 4) == 0.1234 and learning.java_round(0.12345, 4) == 0.1235
+
+
+@pytest.mark.gpu
+def test_reference_lambdamart_behaviour_through_the_cli(tmp_path):
+    data, model, run, sc = (str(tmp_path / n) for n in ("data.txt", "model.txt", "run.txt", "scores.txt"))
+    write_random_data(data)
+    saved = (learning.LambdaMART.nTrees, learning.LambdaMART.nTreeLeaves)
+    try:
+        evaluator.main(["-train", data, "-metric2t", "NDCG@10", "-ranker", "6", "-tree", "30", "-save", model])
+        evaluator.main(["-rank", data, "-load", model, "-indri", run])
+        evaluator.main(["-rank", data, "-load", model, "-score", sc])
+    finally:
+        learning.LambdaMART.nTrees, learning.LambdaMART.nTreeLeaves = saved
+    text = open(model).read()
+    assert text.startswith("## LambdaMART\n## No. of trees = 30\n## No. of leaves = 10\n")
+    # test:eval/EvaluatorTest.java:238-255
+    best_p, best_n = 10 ** 9, 10 ** 9
+    for line in open(run):
+        row = line.split()
+        assert row[1] == "Q0" and row[5] == "indri"
+        score = float(row[4])
+        assert np.isfinite(score)
+        rank = int(row[3])
+        if row[2].startswith("P"):
+            best_p = min(best_p, rank)
+        else:
+            best_n = min(best_n, rank)
+    assert best_p == 1 and best_p < best_n
+    rows = [l.split("\t") for l in open(sc)]
+    assert len(rows) == 200 and rows[0][0] == "x" and rows[5][1] == "5"
