@@ -1,0 +1,74 @@
+"""Generates tests/golden/*.npz from the CPU oracle (oracle/rl_oracle.c).
+
+The reference (Java) cannot run in this environment and its own tests hold no numeric vectors for this path, so
+these fixtures are ORACLE outputs, not Java outputs ("parity unpinned").  They pin the oracle against
+accidental drift (tests/test_golden.py, CPU) and give the HIP path a committed, reference-free target (-m gpu).
+A fixture is data only: the inputs (X, labels, query offsets) and the expected outputs.
+
+    python tests/golden/make_fixtures.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import oracle_ffi as O  # noqa: E402
+from ranklib_amd import synth  # noqa: E402
+
+CASES = {
+    # name: (n_docs, n_features, kind, seed, params)
+    "small_ns": (600, 6, "ns", 101, dict(n_trees=6, n_leaves=8, mls=1, k=10, n_threshold=256, lr=0.1)),
+    "small_mslr_k3": (900, 5, "mslr", 102, dict(n_trees=5, n_leaves=6, mls=4, k=3, n_threshold=16, lr=0.05)),
+    "valid_estop": (700, 4, "ns", 103, dict(n_trees=40, n_leaves=6, mls=1, k=10, n_threshold=256, lr=0.3, early_stop=2)),
+}
+
+
+def run(name):
+    n_docs, n_feat, kind, seed, p = CASES[name]
+    X, lab, qoff = synth.make_dataset(n_docs, n_feat, kind, seed_offset=seed)
+    o = O.Oracle(X, lab, qoff, **p)
+    out = dict(X=X, labels=lab, qoff=qoff, params=np.array(sorted(p.items()), dtype=object))
+    if "early_stop" in p:
+        Xv, lv, qv = synth.make_dataset(500, n_feat, kind, seed_offset=seed + 50)
+        o.set_validation(Xv, lv, qv)
+        out.update(Xv=Xv, labels_v=lv, qoff_v=qv)
+    o.init()
+    out["nbins"] = np.array([o.n_bins(f) for f in range(n_feat)], np.int32)
+    for f in range(n_feat):
+        out["thr%d" % f] = o.thresholds(f)
+        out["bins%d" % f] = o.bins(f).astype(np.uint16)
+    tm_all, vm_all, rounds = [], [], 0
+    for r in range(p["n_trees"]):
+        t, tm, vm, stop = o.round()
+        tr = t.trimmed()
+        for k in ("feature", "threshold", "left", "right", "output", "count"):
+            out["tree%d_%s" % (r, k)] = tr[k]
+        if r < 3:
+            out["lambda%d" % r] = o.lambdas()
+            out["weight%d" % r] = o.weights()
+        tm_all.append(tm)
+        vm_all.append(vm if vm is not None else np.float32(0))
+        rounds += 1
+        if stop:
+            break
+    out["scores"] = o.scores()
+    out["train_metric"] = np.array(tm_all, np.float32)
+    out["valid_metric"] = np.array(vm_all, np.float32)
+    out["rounds"] = np.int32(rounds)
+    ts, vs = o.finish()
+    out["final_train"] = np.float64(ts)
+    out["final_valid"] = np.float64(vs if vs is not None else 0.0)
+    out["trees_kept"] = np.int32(o.trees_kept())
+    out["predict_head"] = o.predict(X[:64])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "rounds", rounds, "kept", int(out["trees_kept"]), "final", float(out["final_train"]))
+
+
+if __name__ == "__main__":
+    for n in CASES:
+        run(n)

@@ -1,0 +1,93 @@
+"""-m gpu: size-independent properties at BASELINE.json's full sizes (the oracle would take minutes there).
+
+c1 = MSLR-WEB10K-shape (1.2 M docs), c2 = MSLR-WEB30K-shape (3.77 M docs), both 136 features / 31 leaves.
+Checked per round:
+  * conservation: every feature's last cumulative root bin is the SAME exact 128-bit sum and equals sum(q);
+    root counts end at N; node counts: parent = left + right, leaves partition the training set
+  * the exact parallel float chains: every leaf output equals the literal serial Java float running sums of the
+    leaf's lambdas / weights (serial C loop from the test infrastructure), same for the per-round metric mean
+  * score update: every document moved by exactly lr * (output of the leaf it fell into)
+  * determinism: a second run from scratch produces byte-identical trees / scores
+"""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+from ranklib_amd import _native as N
+from ranklib_amd import synth
+from tree_equiv import node_members
+
+pytestmark = pytest.mark.gpu
+
+
+def run(shape, rounds, keep_arrays):
+    n_docs, n_feat, kind, _, n_leaves = synth.SHAPES[shape]
+    X, lab, qoff, Q = synth.make_shard(n_docs, n_feat, kind, 0, 1)
+    g = N.Trainer(n_trees=rounds, n_leaves=n_leaves)
+    g.set_train(X, lab, qoff)
+    g.init()
+    out = []
+    prev = np.zeros(n_docs)
+    for r in range(rounds):
+        t, tm, _, _ = g.boost_round()
+        rec = dict(tree=t.trimmed(), tm=tm, score=g.array("SCORE"))
+        if keep_arrays:
+            rec.update(lam=g.array("LAMBDA"), w=g.array("WEIGHT"), q=g.array("QUANT"), fixed=g.array("ROOT_SUM_FIXED"),
+                       cnt=g.array("ROOT_COUNT"), nb=g.array("NBINS"), ndcg=g.array("NDCG_PER_QUERY"), prev=prev)
+        prev = rec["score"]
+        out.append(rec)
+    return X, lab, qoff, out, g.array("CHAIN_STATS")
+
+
+@pytest.mark.parametrize("shape,rounds", [("c1", 3), ("c2", 2)])
+def test_fullsize_invariants(shape, rounds):
+    X, lab, qoff, recs, stats = run(shape, rounds, True)
+    n = X.shape[0]
+    lr = np.float64(np.float32(0.1))
+    for r, rec in enumerate(recs):
+        tr = rec["tree"]
+        # --- exact conservation of the fixed-point histogram
+        tot = int(rec["q"].astype(object).sum())
+        for f in range(X.shape[1]):
+            T = rec["nb"][f]
+            hi, lo = int(rec["fixed"][f, T - 1, 0]), int(rec["fixed"][f, T - 1, 1]) & 0xFFFFFFFFFFFFFFFF
+            assert hi * 2 ** 64 + lo == tot, (r, f)
+            assert rec["cnt"][f, T - 1] == n
+        # --- tree bookkeeping
+        internal = np.nonzero(tr["feature"] != -1)[0]
+        for i in internal:
+            assert tr["count"][i] == tr["count"][tr["left"][i]] + tr["count"][tr["right"][i]]
+        leaves = np.nonzero(tr["feature"] == -1)[0]
+        assert tr["count"][leaves].sum() == n and tr["count"][0] == n and len(leaves) == 31
+        mem = node_members(tr, X)
+        for i in range(len(tr["feature"])):
+            assert len(mem[i]) == tr["count"][i], (r, i)
+        # --- leaf outputs == literal Java float running sums (LambdaMART.java:401-413)
+        leaf_of = np.zeros(n, np.int32)
+        for i in leaves:
+            idx = mem[i].astype(np.int32)
+            s1, s2 = O.float_chain(rec["lam"], idx), O.float_chain(rec["w"], idx)
+            exp = np.float32(0) if s2 == 0 else np.float32(s1 / s2)
+            assert np.float32(tr["output"][i]).view(np.uint32) == exp.view(np.uint32), (r, i, len(idx))
+            leaf_of[idx] = i
+        # --- score update: modelScores[k] += learningRate * output   (:208)
+        exp_scores = rec["prev"] + lr * tr["output"][leaf_of].astype(np.float64)
+        assert np.array_equal(exp_scores.view(np.int64), rec["score"].view(np.int64)), r
+        # --- per-round metric: float running sum of the per-query NDCG values, / Q in float (:469-483)
+        nd = rec["ndcg"]
+        assert nd.min() >= 0.0 and nd.max() <= 1.0
+        s = O.float_chain(nd)
+        assert np.float32(rec["tm"]).view(np.uint32) == np.float32(s / np.float32(len(nd))).view(np.uint32), r
+    assert stats[2] == 0 and stats[5] == 0, "serial finish of a float chain was needed: %s" % stats
+    print("%s: float chains evaluated %d, window misses repaired %d, metric chains %d (misses %d)" %
+          (shape, stats[0], stats[1], stats[3], stats[4]))
+
+
+def test_fullsize_determinism_c1():
+    _, _, _, a, _ = run("c1", 3, False)
+    _, _, _, b, _ = run("c1", 3, False)
+    for x, y in zip(a, b):
+        assert x["tm"] == y["tm"]
+        assert np.array_equal(x["score"].view(np.int64), y["score"].view(np.int64))
+        for k in ("feature", "threshold", "left", "right", "output", "count"):
+            assert np.array_equal(x["tree"][k], y["tree"][k])
