@@ -32,6 +32,17 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s measured float4 copy
 
 
+def pmc_traffic(shape, world):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass (profiles/r01_pmc_root_hist.json:
+    2 x FETCH_SIZE (gfx950 half-count correction) + WRITE_SIZE); null when no pass exists for this workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_root_hist.json")) as f:
+            d = json.load(f)
+        return float(d[shape]["traffic_bytes"]) if world == 1 and shape in d else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,7 +151,7 @@ def main():
         out["roofline"] = {
             "kernel": "rl::k_hist<true,16> (root histogram, FeatureHistogram.update)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": pmc_traffic(args.shape, world),
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": per_launch_ms, "launches": int(n_root),
             "note": "algorithmic bytes = N_local*(F*2 B bin ids + 8 B fixed-point lambda); HIP events on the library stream",
         }
