@@ -116,6 +116,7 @@ def main():
     ms_root, n_root, bytes_root = g.timing("HIST_ROOT")
     ms_node, n_node, _ = g.timing("HIST_NODE")
     ms_lam, n_lam, _ = g.timing("LAMBDA")
+    gs = g.array("GROW_STATS")
 
     if rank != 0:
         return
@@ -142,6 +143,9 @@ def main():
             "docs_total": n_docs, "docs_rank0": int(X.shape[0]), "features": n_feat, "queries_total": q_total, "leaves": n_leaves,
             "ndcg10_train_after_%d_rounds" % total_rounds: ndcg_t,
             "init_seconds": round(t_init, 3), "datagen_seconds": round(t_gen, 3),
+            "growth_steps_per_tree": round(float(gs[0]) / max(int(gs[3]), 1), 2),
+            "nodes_prepared_per_tree": round(float(gs[1]) / max(int(gs[3]), 1), 2),
+            "splits_per_tree": round(float(gs[2]) / max(int(gs[3]), 1), 2),
         },
     }
     if n_root > 0:

@@ -191,7 +191,9 @@ enum {
     RL_ARR_NDCG_PER_QUERY = 12, /* double[n_queries] of the last round */
     RL_ARR_CHAIN_STATS = 13,    /* int32[6]: leaf float chains {evaluated, candidate-window misses repaired, finished
                                    by the serial kernel}; the same three for the per-round metric chain */
-    RL_ARR_CHAIN_MISS = 14      /* int32[2*(2*n_leaves)]: per (value array, leaf slot) window misses of the last round */
+    RL_ARR_CHAIN_MISS = 14,     /* int32[2*(2*n_leaves)]: per (value array, leaf slot) window misses of the last round */
+    RL_ARR_GROW_STATS = 15      /* int32[4] cumulative: growth steps run, nodes prepared (partition + child histograms),
+                                   splits committed to trees, trees grown -- speculative best-first growth */
 };
 int rl_bin_stride(const rl_trainer *t, int32_t *stride);
 int rl_quant_exponent(const rl_trainer *t, int32_t *e);   /* q = rint(lambda * 2^e) in the last round */

@@ -21,6 +21,7 @@ constexpr int kHistFG = 16;          // features per group of the histogram layo
 constexpr int kPartTile = 2048;      // docs per partition tile (256 threads x 8)
 constexpr int kMaxBins = 4096;       // bin stride limit (thresholds per feature incl. MAX_VALUE)
 constexpr int kHistLdsBytes = 64 * 1024;
+constexpr int kSpec = 4;             // nodes split (speculatively, in queue order) per growth step
 constexpr int kLambdaWaveCap = 384;  // docs/query handled by the wave-per-query lambda kernel
 constexpr int kLambdaBlockCap = 5000;
 constexpr int kLambdaFusedMaxK = 16;  // NDCG@k up to this k uses the LDS-resident fused lambda kernel
@@ -41,16 +42,33 @@ struct NodeRec {
     long long tot_hi; unsigned long long tot_lo;   // exact 128-bit fixed-point sum of lambda
     long long sq;            // exact fixed-point sum of lambda^2
     float   output; int32_t gcount;   // gcount: samples of the node over ALL ranks (== count on one GPU)
+    // speculative growth: a node is PREPARED once its samples are partitioned and its children (pl, pr) have their
+    // histograms and best splits; it becomes internal (left/right set) only when RegressionTree.fit's loop pops it.
+    int32_t pl, pr;          // prepared children, -1 while unprepared
+    int32_t fid;             // id in the exported tree (creation order of the COMMITTED splits), -1 = not part of the tree
+    int32_t prepared;
+    int32_t best_cl, pad_;   // cumulative histogram entry at the best split: count ...
+    long long best_hi; unsigned long long best_lo;   // ... and exact fixed-point sum (= the left child's totals)
+};
+
+// one node being split in the current growth step
+struct SlotRec {
+    int32_t node, left, right, build_left;   // parent, its prepared children, which child is histogrammed from samples
+    int32_t pstart, pcount, pbuf, f, t;      // parent's local sample range and split (copied: saves a dependent load)
+    int32_t tile0, ntiles;                   // partition tiles [tile0, tile0+ntiles) of this step's grid
+    int32_t chunk0, nchunks;                 // histogram chunks [chunk0, chunk0+nchunks) (upper bound) of this step's grid
+    int32_t nleft;                           // local size of the left child when known in advance (one GPU), else -1
+    long long sq_left;                       // fixed-point sum of lambda^2 over the left child (k_part_scatter)
 };
 
 struct TreeState {
-    int32_t n_nodes, cur, done, taken;
-    int32_t qsize, new_left, new_right, n_leaves;
-    int32_t E, E2, n_splits, error;
-    int32_t build_left, pad0, pad1, pad2;   // which child of the current split is histogrammed from its samples
+    int32_t n_nodes, nslots, done, taken;
+    int32_t qsize, n_leaves, E, E2;
+    int32_t n_splits, error, tiles_total, chunks_total;
+    int32_t arrive, epoch, pad0, pad1;    // finish blocks arrived (last one runs select_step); growth step counter (look-back tags)
     unsigned long long maxabs_bits;   // max |lambda| of the round (bit pattern, monotone for x >= 0)
     long long root_sq;                // sum over all docs of rint(lambda^2 * 2^E2)
-    long long sq_left;                // same over the left child being built
+    SlotRec slot[kSpec];
 };
 
 // one kept tree of the ensemble, nodes in creation order
@@ -59,10 +77,10 @@ struct TreeSlot {
 };
 
 struct Ctx {
-    int32_t N, Npad, Q, F, TS, L, MAXN, mls, k, maxChunks, nTiles, FG, numFG;
+    int32_t N, Npad, Q, F, TS, L, MAXN, NC, mls, k, maxChunks, nTiles, FG, numFG;   // MAXN = 2L-1 tree nodes, NC = node records incl. speculation
     float lr;
     int32_t rank, n_ranks;
-    long long *dist_buf;     // [F*TS*3 + 4] int64 limbs of the histogram being all-reduced (multi-GPU only)
+    long long *dist_buf;     // [kSpec][F*TS*3 + 4] int64 limbs of the histograms being all-reduced (multi-GPU only)
     // static per data set
     const uint16_t *bins;   // [F][Npad]  feature-major: single-column scans (partition)
     const uint16_t *gbins;  // [numFG][Npad][kHistFG]  group-major: one 32-byte row per document and group (histograms)
@@ -80,15 +98,21 @@ struct Ctx {
     long long *q, *r;
     int32_t *idx[2];
     long long *ql[2];        // fixed-point lambda in sample-list order (travels with idx through the partitions)
+    long long *rl[2];        // fixed-point lambda^2, likewise
+    unsigned long long *tile_desc;   // [nTiles] look-back descriptors of the single-pass partition
     NodeRec *nodes;
     TreeState *st;
     int32_t *queue;
     long long *cum_hi; unsigned long long *cum_lo; int32_t *cum_cnt;   // [MAXN][F][TS] cumulative
     long long *part_sum; int32_t *part_cnt;                            // [maxChunks][F][TS]
     long long *part_tot;                                               // [maxChunks] sum of q over the chunk's samples
-    double *fb_S; int32_t *fb_t;                                       // [2][F]
+    double *fb_S; int32_t *fb_t;                                       // [kSpec][2][F] per-feature best split of each new node ...
+    int32_t *fb_cl; long long *fb_hi; unsigned long long *fb_lo;      // ... with the cumulative histogram entry there
+    unsigned long long *fb_root;                                       // [2] exact root total of the round
     int32_t *tile_cnt;                                                 // [nTiles]
+    long long *tile_sq;                                                // [nTiles] lambda^2 partial of each partition tile's left members
     int32_t *leaf_node, *leaf_start;                                   // [MAXN], [MAXN+1]
+    int32_t *grow_stats;                                               // [4] cumulative: growth steps, nodes prepared, splits committed, trees
     float *round_metric;                                               // [n_trees][2]
 };
 

@@ -328,7 +328,7 @@ static int enqueue_round(rl_trainer *t)
     hipStream_t s = t->stream;
     const int m = t->round;
     // round scalars
-    RL_HIP(hipMemsetAsync(&c.st->maxabs_bits, 0, sizeof(unsigned long long) + 2 * sizeof(long long), s));
+    RL_HIP(hipMemsetAsync(&c.st->maxabs_bits, 0, sizeof(unsigned long long) + sizeof(long long), s));
     {   // K1 lambdas: pair terms in parallel, then ordered accumulation (ranked order comes from the previous
         // round's k_rank_* / from rl_init for round 0)
         ScopedTiming tm(t, RL_KERNEL_LAMBDA, (double)c.N * 28.0);
@@ -349,36 +349,41 @@ static int enqueue_round(rl_trainer *t)
     hipLaunchKernelGGL(k_quantize, dim3(std::min(2048, (c.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, c);
     const size_t hist_lds = (size_t)c.sub * c.TS * 8 + (size_t)c.sub * ((c.TS + 1) / 2) * 4;
     const int hist_gx = c.numFG * (kHistFG / c.sub);
-    const size_t fin_lds = (size_t)c.TS * 20;
+    const size_t red_lds = (size_t)c.TS * 20;
     const int rootCs = std::min(kChunk, std::max(kMinChunk, (((c.N + 63) / 64 + 255) & ~255)));   // == chunk_docs<true>(N)
     const int rootChunks = (c.N + rootCs - 1) / rootCs;
     {   // K2 root histogram
         ScopedTiming tm(t, RL_KERNEL_HIST_ROOT, (double)c.N * ((double)c.F * 2.0 + 8.0));
         launch_hist<true>(c, hist_gx, rootChunks, hist_lds, s);
     }
+    // the last block of k_hist_finish runs the growth bookkeeping (select_step); node records live in LDS when they fit
+    const int nodes_in_lds = (select_lds_bytes(c.L, c.NC, true) <= 60 * 1024) ? 1 : 0;
+    const size_t fin_lds = std::max((size_t)c.TS * 20, select_lds_bytes(c.L, c.NC, nodes_in_lds != 0));
     if (t->dist) {
-        hipLaunchKernelGGL(k_hist_reduce, dim3(c.F), dim3(kThreads), fin_lds, s, c, 1);
+        hipLaunchKernelGGL(k_hist_reduce, dim3(c.F), dim3(kThreads), red_lds, s, c, 1);
         int rcd = t->dist->allreduce(c.dist_buf, (size_t)c.F * c.TS * 3 + 4, DT_I64, OP_SUM, s);
         if (rcd) return rcd;
-        hipLaunchKernelGGL((k_hist_finish<true, true>), dim3(c.F), dim3(kThreads), fin_lds, s, c);
-    } else hipLaunchKernelGGL((k_hist_finish<true, false>), dim3(c.F), dim3(kThreads), fin_lds, s, c);
-    const size_t sel_lds = ((sizeof(SelShared) + 15) & ~(size_t)15) + (size_t)(c.MAXN + 2) * 12;
-    hipLaunchKernelGGL(k_select, dim3(1), dim3(64), sel_lds, s, c, 1);
+        hipLaunchKernelGGL((k_hist_finish<true, true>), dim3(c.F), dim3(kThreads), fin_lds, s, c, nodes_in_lds);
+    } else hipLaunchKernelGGL((k_hist_finish<true, false>), dim3(c.F), dim3(kThreads), fin_lds, s, c, nodes_in_lds);
+    // Growth steps: each prepares up to kSpec queue nodes and commits as many splits as the fit loop allows; L-1 steps
+    // always suffice (every step commits at least the head of the queue); finished trees make the rest no-ops.
     const int steps = c.L - 1;
+    const size_t slot_words = (size_t)c.F * c.TS * 3 + 4;
     for (int it = 0; it < steps; it++) {
-        hipLaunchKernelGGL(k_part_count, dim3(c.nTiles), dim3(kThreads), 0, s, c);
-        hipLaunchKernelGGL(k_part_scatter, dim3(c.nTiles), dim3(kThreads), 0, s, c);
+        if (t->dist) {      // local child sizes are unknown in advance: count pass, then scatter
+            hipLaunchKernelGGL(k_part_count, dim3(c.nTiles), dim3(kThreads), 0, s, c);
+            hipLaunchKernelGGL(k_part_scatter<false>, dim3(c.nTiles), dim3(kThreads), 0, s, c);
+        } else hipLaunchKernelGGL(k_part_scatter<true>, dim3(c.nTiles), dim3(kThreads), 0, s, c);
         {
             ScopedTiming tm(t, RL_KERNEL_HIST_NODE, 0.0);
             launch_hist<false>(c, hist_gx, c.maxChunks, hist_lds, s);
         }
         if (t->dist) {
-            hipLaunchKernelGGL(k_hist_reduce, dim3(c.F), dim3(kThreads), fin_lds, s, c, 0);
-            int rcd = t->dist->allreduce(c.dist_buf, (size_t)c.F * c.TS * 3 + 4, DT_I64, OP_SUM, s);
+            hipLaunchKernelGGL(k_hist_reduce, dim3(c.F, kSpec), dim3(kThreads), red_lds, s, c, 0);
+            int rcd = t->dist->allreduce(c.dist_buf, slot_words * kSpec, DT_I64, OP_SUM, s);
             if (rcd) return rcd;
-            hipLaunchKernelGGL((k_hist_finish<false, true>), dim3(c.F), dim3(kThreads), fin_lds, s, c);
-        } else hipLaunchKernelGGL((k_hist_finish<false, false>), dim3(c.F), dim3(kThreads), fin_lds, s, c);
-        hipLaunchKernelGGL(k_select, dim3(1), dim3(64), sel_lds, s, c, 0);
+            hipLaunchKernelGGL((k_hist_finish<false, true>), dim3(c.F, kSpec), dim3(kThreads), fin_lds, s, c, nodes_in_lds);
+        } else hipLaunchKernelGGL((k_hist_finish<false, false>), dim3(c.F, kSpec), dim3(kThreads), fin_lds, s, c, nodes_in_lds);
     }
     hipLaunchKernelGGL(k_leaf_table, dim3(1), dim3(64), 0, s, c, t->leaf_chain, t->d_seg_buf);
     if (t->p.flags & RL_FLAG_SERIAL_CHAIN) {
@@ -635,6 +640,7 @@ int rl_init(rl_trainer *t)
     const int N = (int)t->tr.N, F = t->F;
     const int Npad = (N + 127) / 128 * 128;
     c.N = N; c.Npad = Npad; c.Q = t->tr.Q; c.F = F; c.L = t->p.n_leaves; c.MAXN = 2 * t->p.n_leaves - 1;
+    c.NC = 4 * t->p.n_leaves + 2;     // node records: committed (2L-1) + prepared but never reached (see k_select)
     c.mls = t->p.min_leaf_support; c.k = t->p.metric_k; c.lr = t->p.learning_rate;
     c.rank = t->rank; c.n_ranks = t->n_ranks;
 
@@ -711,11 +717,12 @@ int rl_init(rl_trainer *t)
     RL_HIP(t->pool.alloc(&d_gbins, (size_t)c.numFG * Npad * kHistFG));
     RL_HIP(hipMemsetAsync(d_gbins, 0, (size_t)c.numFG * Npad * kHistFG * sizeof(uint16_t), s));
     c.bins = d_bins; c.gbins = d_gbins;
-    c.maxChunks = std::max((N + kNodeChunk - 1) / kNodeChunk, 64) + 1;      // see chunk_docs()
-    c.nTiles = (N + kPartTile - 1) / kPartTile;
-    RL_HIP(t->pool.alloc(&c.cum_hi, (size_t)c.MAXN * F * TS));
-    RL_HIP(t->pool.alloc(&c.cum_lo, (size_t)c.MAXN * F * TS));
-    RL_HIP(t->pool.alloc(&c.cum_cnt, (size_t)c.MAXN * F * TS));
+    // chunks of one growth step (all slots; see prepare_children), and of the root pass
+    c.maxChunks = N / kNodeChunk + 67 * kSpec + 2;
+    c.nTiles = (N + kPartTile - 1) / kPartTile + kSpec;      // tiles of one growth step (disjoint nodes, one ragged tile each)
+    RL_HIP(t->pool.alloc(&c.cum_hi, (size_t)c.NC * F * TS));
+    RL_HIP(t->pool.alloc(&c.cum_lo, (size_t)c.NC * F * TS));
+    RL_HIP(t->pool.alloc(&c.cum_cnt, (size_t)c.NC * F * TS));
     RL_HIP(hipMemsetAsync(c.cum_cnt, 0, (size_t)F * TS * sizeof(int32_t), s));
     hipLaunchKernelGGL(k_binning, dim3(F, slices), dim3(kThreads), (size_t)TS * 8, s, (const float *)Xt, N, Npad, TS, (const float *)d_thr,
                        (const int32_t *)d_nthr, d_bins, d_gbins, c.cum_cnt);
@@ -772,14 +779,19 @@ int rl_init(rl_trainer *t)
     RL_HIP(t->pool.alloc(&c.q, (size_t)N)); RL_HIP(t->pool.alloc(&c.r, (size_t)N));
     RL_HIP(t->pool.alloc(&c.idx[0], (size_t)N)); RL_HIP(t->pool.alloc(&c.idx[1], (size_t)N));
     RL_HIP(t->pool.alloc(&c.ql[0], (size_t)N)); RL_HIP(t->pool.alloc(&c.ql[1], (size_t)N));
-    RL_HIP(t->pool.alloc(&c.nodes, (size_t)c.MAXN + 2)); RL_HIP(t->pool.alloc(&c.st, (size_t)1));
+    RL_HIP(t->pool.alloc(&c.rl[0], (size_t)N)); RL_HIP(t->pool.alloc(&c.rl[1], (size_t)N));
+    RL_HIP(t->pool.alloc(&c.nodes, (size_t)c.NC + 2)); RL_HIP(t->pool.alloc(&c.st, (size_t)1));
     RL_HIP(hipMemset(c.st, 0, sizeof(TreeState)));
-    RL_HIP(hipMemset(c.nodes, 0, ((size_t)c.MAXN + 2) * sizeof(NodeRec)));
+    RL_HIP(hipMemset(c.nodes, 0, ((size_t)c.NC + 2) * sizeof(NodeRec)));
     RL_HIP(t->pool.alloc(&c.queue, (size_t)c.MAXN + 2));
     RL_HIP(t->pool.alloc(&c.part_sum, (size_t)c.maxChunks * F * TS)); RL_HIP(t->pool.alloc(&c.part_cnt, (size_t)c.maxChunks * F * TS));
     RL_HIP(t->pool.alloc(&c.part_tot, (size_t)std::max(c.maxChunks, (N + kMinChunk - 1) / kMinChunk) + 1));
-    RL_HIP(t->pool.alloc(&c.fb_S, (size_t)2 * F)); RL_HIP(t->pool.alloc(&c.fb_t, (size_t)2 * F));
-    RL_HIP(t->pool.alloc(&c.tile_cnt, (size_t)c.nTiles));
+    RL_HIP(t->pool.alloc(&c.fb_S, (size_t)kSpec * 2 * F)); RL_HIP(t->pool.alloc(&c.fb_t, (size_t)kSpec * 2 * F));
+    RL_HIP(t->pool.alloc(&c.fb_cl, (size_t)kSpec * 2 * F)); RL_HIP(t->pool.alloc(&c.fb_hi, (size_t)kSpec * 2 * F));
+    RL_HIP(t->pool.alloc(&c.fb_lo, (size_t)kSpec * 2 * F)); RL_HIP(t->pool.alloc(&c.fb_root, (size_t)2));
+    RL_HIP(t->pool.alloc(&c.tile_cnt, (size_t)c.nTiles)); RL_HIP(t->pool.alloc(&c.tile_sq, (size_t)c.nTiles));
+    RL_HIP(t->pool.alloc(&c.tile_desc, (size_t)c.nTiles)); RL_HIP(hipMemset(c.tile_desc, 0, (size_t)c.nTiles * 8));
+    RL_HIP(t->pool.alloc(&c.grow_stats, (size_t)4)); RL_HIP(hipMemset(c.grow_stats, 0, 16));
     RL_HIP(t->pool.alloc(&c.leaf_node, (size_t)c.MAXN + 1)); RL_HIP(t->pool.alloc(&c.leaf_start, (size_t)c.MAXN + 2));
     RL_HIP(t->pool.alloc(&c.round_metric, (size_t)2 * t->p.n_trees));
     RL_HIP(hipMemset(c.round_metric, 0, (size_t)2 * t->p.n_trees * sizeof(float)));
@@ -828,8 +840,8 @@ int rl_init(rl_trainer *t)
             RL_HIP(t->pool.alloc(&t->d_qcat, (size_t)t->Qglobal)); RL_HIP(t->pool.alloc(&t->d_allQ, (size_t)t->n_ranks));
             RL_HIP(hipMemcpy(t->d_allQ, t->all_Q.data(), t->n_ranks * sizeof(int32_t), hipMemcpyHostToDevice));
             RL_HIP(hipMemset(t->d_qsend, 0, (size_t)t->Qmax * sizeof(double)));
-            RL_HIP(t->pool.alloc(&c.dist_buf, (size_t)F * TS * 3 + 4));
-            RL_HIP(hipMemset(c.dist_buf, 0, ((size_t)F * TS * 3 + 4) * sizeof(long long)));
+            RL_HIP(t->pool.alloc(&c.dist_buf, ((size_t)F * TS * 3 + 4) * kSpec));
+            RL_HIP(hipMemset(c.dist_buf, 0, ((size_t)F * TS * 3 + 4) * kSpec * sizeof(long long)));
         }
     }
     {   // ranked-order arrays + pair-term matrix of the lambda kernels
@@ -1105,6 +1117,7 @@ int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes)
     case RL_ARR_ROOT_COUNT: src = c.cum_cnt; bytes = (size_t)c.F * c.TS * 4; break;
     case RL_ARR_QUANT: src = c.q; bytes = (size_t)c.N * 8; break;
     case RL_ARR_NDCG_PER_QUERY: src = c.ndcg_q; bytes = (size_t)c.Q * 8; break;
+    case RL_ARR_GROW_STATS: src = c.grow_stats; bytes = 16; break;
     case RL_ARR_CHAIN_STATS: {
         if (cap_bytes < 24) return fail(RL_ERR_INVALID, "output buffer too small");
         RL_HIP(hipMemcpy(out, (t->dist ? t->gchain : t->leaf_chain).stats, 12, hipMemcpyDeviceToHost));
