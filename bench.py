@@ -159,8 +159,7 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": per_launch_ms, "launches": int(n_root),
             "note": "algorithmic bytes = N_local*(F*2 B bin ids + 8 B fixed-point lambda); HIP events on the library stream",
         }
-        out["kernel_ms_per_round"] = {"hist_root": ms_root / args.steps, "hist_node": ms_node / args.steps,
-                                      "lambda": ms_lam / args.steps}
+        out["kernel_ms_per_round"] = {"hist_root": ms_root / args.steps, "lambda": ms_lam / args.steps}
 
     if args.cpu_rounds > 0 and world == 1:
         import oracle_ffi as O

@@ -59,7 +59,8 @@ enum { RL_METRIC_NDCG = 0 };            /* metric/NDCGScorer.java (others: SURVE
 enum {                                  /* rl_params.flags */
     RL_FLAG_FAST_LEAF = 1,              /* leaf sums as exact-f64 tree sums instead of emulating the Java float
                                            running sums (learning/tree/LambdaMART.java:401-408).  NOT parity. */
-    RL_FLAG_TIMING = 2,                 /* record HIP events around the dominant kernels (rl_get_timing) */
+    RL_FLAG_TIMING = 2,                 /* record HIP events around the root histogram and the lambda kernels (rl_get_timing) */
+    RL_FLAG_TIMING_NODES = 8,           /* ... and around every growth step's node-histogram launch (30 event pairs per round) */
     RL_FLAG_SERIAL_CHAIN = 4            /* evaluate the float running sums with the literal serial kernel instead of
                                            the exact parallel scheme (same results; for cross-checks) */
 };

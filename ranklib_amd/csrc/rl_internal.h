@@ -76,6 +76,7 @@ struct TreeSlot {
     int32_t n_nodes, pad;
 };
 
+struct FeatBest;
 struct Ctx {
     int32_t N, Npad, Q, F, TS, L, MAXN, NC, mls, k, maxChunks, nTiles, FG, numFG;   // MAXN = 2L-1 tree nodes, NC = node records incl. speculation
     float lr;
@@ -106,8 +107,7 @@ struct Ctx {
     long long *cum_hi; unsigned long long *cum_lo; int32_t *cum_cnt;   // [MAXN][F][TS] cumulative
     long long *part_sum; int32_t *part_cnt;                            // [maxChunks][F][TS]
     long long *part_tot;                                               // [maxChunks] sum of q over the chunk's samples
-    double *fb_S; int32_t *fb_t;                                       // [kSpec][2][F] per-feature best split of each new node ...
-    int32_t *fb_cl; long long *fb_hi; unsigned long long *fb_lo;      // ... with the cumulative histogram entry there
+    struct FeatBest *fb;                                               // [kSpec][2][F] per-feature best split of each new node (rl_kernels_round.inc)
     unsigned long long *fb_root;                                       // [2] exact root total of the round
     int32_t *tile_cnt;                                                 // [nTiles]
     long long *tile_sq;                                                // [nTiles] lambda^2 partial of each partition tile's left members

@@ -193,7 +193,8 @@ static hipEvent_t take_event(rl_trainer *t)
 }
 struct ScopedTiming {
     rl_trainer *t; int which; hipEvent_t a = nullptr, b = nullptr; bool on;
-    ScopedTiming(rl_trainer *t_, int which_, double bytes) : t(t_), which(which_), on((t_->p.flags & RL_FLAG_TIMING) != 0)
+    ScopedTiming(rl_trainer *t_, int which_, double bytes)
+        : t(t_), which(which_), on((t_->p.flags & (which_ == RL_KERNEL_HIST_NODE ? RL_FLAG_TIMING_NODES : RL_FLAG_TIMING)) != 0)
     {
         if (!on) return;
         a = take_event(t); b = take_event(t);
@@ -786,9 +787,7 @@ int rl_init(rl_trainer *t)
     RL_HIP(t->pool.alloc(&c.queue, (size_t)c.MAXN + 2));
     RL_HIP(t->pool.alloc(&c.part_sum, (size_t)c.maxChunks * F * TS)); RL_HIP(t->pool.alloc(&c.part_cnt, (size_t)c.maxChunks * F * TS));
     RL_HIP(t->pool.alloc(&c.part_tot, (size_t)std::max(c.maxChunks, (N + kMinChunk - 1) / kMinChunk) + 1));
-    RL_HIP(t->pool.alloc(&c.fb_S, (size_t)kSpec * 2 * F)); RL_HIP(t->pool.alloc(&c.fb_t, (size_t)kSpec * 2 * F));
-    RL_HIP(t->pool.alloc(&c.fb_cl, (size_t)kSpec * 2 * F)); RL_HIP(t->pool.alloc(&c.fb_hi, (size_t)kSpec * 2 * F));
-    RL_HIP(t->pool.alloc(&c.fb_lo, (size_t)kSpec * 2 * F)); RL_HIP(t->pool.alloc(&c.fb_root, (size_t)2));
+    RL_HIP(t->pool.alloc(&c.fb, (size_t)kSpec * 2 * F)); RL_HIP(t->pool.alloc(&c.fb_root, (size_t)2));
     RL_HIP(t->pool.alloc(&c.tile_cnt, (size_t)c.nTiles)); RL_HIP(t->pool.alloc(&c.tile_sq, (size_t)c.nTiles));
     RL_HIP(t->pool.alloc(&c.tile_desc, (size_t)c.nTiles)); RL_HIP(hipMemset(c.tile_desc, 0, (size_t)c.nTiles * 8));
     RL_HIP(t->pool.alloc(&c.grow_stats, (size_t)4)); RL_HIP(hipMemset(c.grow_stats, 0, 16));
