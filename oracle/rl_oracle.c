@@ -400,20 +400,126 @@ static double ndcg_score_ranked(ro_trainer *t, const int32_t *rel, int32_t n, in
     return dcg / ideal;
 }
 
+/* APScorer.swapChange (metric/APScorer.java:108-162) on float labels in ranked order; changes = n*n row-major.
+ * K is ignored ("consider the entire ranked list"); no external relevance judgments (relDocCount == null). */
+static void ap_swap_change(const float *lab, int32_t n, double *changes)
+{
+    int32_t *relCount = (int32_t *)malloc(sizeof(int32_t) * (size_t)(2 * n + 2)), *labels = relCount + n + 1;
+    int32_t count = 0;
+    for (int32_t i = 0; i < n; i++) {
+        if (lab[i] > 0) { labels[i] = 1; count++; } else labels[i] = 0;       /* :113-121 (float compare) */
+        relCount[i] = count;
+    }
+    const int32_t rdCount = count;                                            /* :131-133 */
+    memset(changes, 0, sizeof(double) * (size_t)n * (size_t)n);
+    if (rdCount == 0 || count == 0) { free(relCount); return; }               /* :141-143 */
+    for (int32_t i = 0; i < n - 1; i++)
+        for (int32_t j = i + 1; j < n; j++) {
+            double change = 0;
+            if (labels[i] != labels[j]) {
+                const int32_t diff = labels[j] - labels[i];
+                change += ((double)((relCount[i] + diff) * labels[j] - relCount[i] * labels[i])) / (i + 1);   /* :150 */
+                for (int32_t k = i + 1; k <= j - 1; k++) if (labels[k] > 0) change += ((double)diff) / (k + 1);
+                change += ((double)(-relCount[j] * diff)) / (j + 1);                                           /* :156 */
+            }
+            changes[(size_t)j * n + i] = changes[(size_t)i * n + j] = change / rdCount;                        /* :159 */
+        }
+    free(relCount);
+}
+
+static double err_R(int32_t rel) { return ((1 << rel) - 1) / 16.0; }          /* ERRScorer.java:26,71-73 (MAX = 16) */
+
+/* ERRScorer.swapChange (metric/ERRScorer.java:76-115): labels, R and np are only filled for the top `size`
+ * positions (the rest stay 0), and np is the running product as written (p *= np[i]). */
+static void err_swap_change(const float *lab, int32_t n, int32_t k, double *changes)
+{
+    const int32_t size = (n > k) ? k : n;
+    int32_t *labels = (int32_t *)calloc((size_t)n + 1, sizeof(int32_t));
+    double *R = (double *)calloc((size_t)(2 * n + 2), sizeof(double)), *np = R + n + 1;
+    double p = 1.0;
+    for (int32_t i = 0; i < size; i++) {
+        labels[i] = (int32_t)lab[i];
+        R[i] = err_R(labels[i]);
+        np[i] = p * (1.0 - R[i]);
+        p *= np[i];
+    }
+    memset(changes, 0, sizeof(double) * (size_t)n * (size_t)n);
+    for (int32_t i = 0; i < size; i++) {
+        const double v1 = 1.0 / (i + 1) * (i == 0 ? 1 : np[i - 1]);
+        double change = 0;
+        for (int32_t j = i + 1; j < n; j++) {
+            if (labels[i] == labels[j]) change = 0;
+            else {
+                change = v1 * (R[j] - R[i]);
+                p = (i == 0 ? 1 : np[i - 1]) * (R[i] - R[j]);
+                for (int32_t kk = i + 1; kk < j; kk++) { change += p * R[kk] / (1 + kk); p *= 1.0 - R[kk]; }
+                change += (np[j - 1] * (1.0 - R[j]) * R[i] / (1.0 - R[i]) - np[j - 1] * R[j]) / (j + 1);
+            }
+            changes[(size_t)j * n + i] = changes[(size_t)i * n + j] = change;
+        }
+    }
+    free(labels); free(R);
+}
+
+/* MetricScorer.score(RankList) on float labels in ranked order: DCGScorer.score (metric/DCGScorer.java:58-71),
+ * APScorer.score (metric/APScorer.java:73-100), ERRScorer.score (metric/ERRScorer.java:45-64). */
+static double dcg_score_ranked(const float *lab, int32_t n, int32_t k)
+{
+    if (n == 0) return 0;
+    int32_t size = k;
+    if (k > n || k <= 0) size = n;
+    double dcg = 0;
+    for (int32_t i = 0; i < size; i++) dcg += gain_of((int32_t)lab[i]) * g_disc[i];
+    return dcg;
+}
+static double ap_score_ranked(const float *lab, int32_t n)
+{
+    double ap = 0.0; int32_t count = 0;
+    for (int32_t i = 0; i < n; i++) if (lab[i] > 0.0) { count++; ap += ((double)count) / (i + 1); }
+    if (count == 0) return 0.0;
+    return ap / count;
+}
+static double err_score_ranked(const float *lab, int32_t n, int32_t k)
+{
+    int32_t size = k;
+    if (k > n || k <= 0) size = n;
+    double s = 0.0, p = 1.0;
+    for (int32_t i = 1; i <= size; i++) {
+        const double R = err_R((int32_t)lab[i - 1]);
+        s += p * R / i;
+        p *= (1.0 - R);
+    }
+    return s;
+}
+
+/* scorer.getK(): APScorer's constructor sets k = 0 (metric/APScorer.java:37-39) and the factory only overrides it
+ * for "MAP@k" (metric/MetricScorerFactory.java:43-57); callers pass that k. */
+
 /* One query of computePseudoResponses (LambdaMART.java:364-394) with
  * NDCGScorer.swapChange (:132-160) evaluated on the fly instead of
- * materialising the n x n matrix (same values, same order of use).
+ * materialising the n x n matrix (same values, same order of use); the other
+ * metrics materialise their matrix like the Java does.
  * scores/labels/lambda/weight are the GLOBAL arrays; docs cur..cur+n-1. */
 static void query_lambdas(const ro_trainer *t, const double *modelScores, const float *labels, int32_t cur,
                           int32_t n, int32_t k, int32_t key, double ideal_override, double *pseudo,
                           double *weights, int32_t *idx, int32_t *tmp, int32_t *rel)
 {
+    const int32_t metric = t ? t->p.metric : (ideal_override <= -2.0 ? (int32_t)(-ideal_override - 2.0) : RO_METRIC_NDCG);
     sort_idx(modelScores, cur, n, 0, idx, tmp, tmp + n);      /* :366 */
     for (int32_t i = 0; i < n; i++) rel[i] = (int32_t)labels[idx[i]]; /* MetricScorer.java:54-60 */
     int32_t size = (n > k) ? k : n;                           /* NDCGScorer.java:133 */
-    double ideal;
-    if (ideal_override >= 0) ideal = ideal_override;
-    else if (!(t && key >= 0 && cache_get(t, key, &ideal))) ideal = ideal_dcg(rel, n, size, tmp); /* :137-143 */
+    double ideal = 1.0;
+    double *changes = NULL;
+    if (metric == RO_METRIC_NDCG) {
+        if (ideal_override >= 0) ideal = ideal_override;
+        else if (!(t && key >= 0 && cache_get(t, key, &ideal))) ideal = ideal_dcg(rel, n, size, tmp); /* :137-143 */
+    } else if (metric == RO_METRIC_MAP || metric == RO_METRIC_ERR) {
+        float *lr = (float *)malloc(sizeof(float) * (size_t)(n + 1));
+        for (int32_t i = 0; i < n; i++) lr[i] = labels[idx[i]];
+        changes = (double *)malloc(sizeof(double) * (size_t)n * (size_t)n + 8);
+        if (metric == RO_METRIC_MAP) ap_swap_change(lr, n, changes); else err_swap_change(lr, n, k, changes);
+        free(lr);
+    }
     const int32_t cutoff = k;                                 /* LambdaMART.java:362 */
     for (int32_t j = 0; j < n; j++) {
         const int32_t mj = idx[j];
@@ -421,11 +527,14 @@ static void query_lambdas(const ro_trainer *t, const double *modelScores, const 
             if (j > cutoff && kk > cutoff) break;             /* :375-377 */
             const int32_t mk = idx[kk];
             if (labels[mj] > labels[mk]) {                    /* :380 float compare */
-                double change = 0.0;                          /* changes[j][kk], NDCGScorer.java:151-157 */
-                if (ideal > 0 && j != kk) {
+                double change = 0.0;
+                if (changes) change = changes[(size_t)j * n + kk];
+                else if (j != kk) {
                     int32_t a = j < kk ? j : kk, b = j < kk ? kk : j;
-                    if (a < size)
-                        change = (g_disc[a] - g_disc[b]) * (gain_of(rel[a]) - gain_of(rel[b])) / ideal;
+                    if (metric == RO_METRIC_NDCG) {           /* changes[j][kk], NDCGScorer.java:151-157 */
+                        if (ideal > 0 && a < size) change = (g_disc[a] - g_disc[b]) * (gain_of(rel[a]) - gain_of(rel[b])) / ideal;
+                    } else if (a < size)                      /* DCGScorer.java:84-88 */
+                        change = (g_disc[a] - g_disc[b]) * (gain_of(rel[a]) - gain_of(rel[b]));
                 }
                 const double deltaNDCG = fabs(change);        /* :381 */
                 if (deltaNDCG > 0) {
@@ -440,6 +549,48 @@ static void query_lambdas(const ro_trainer *t, const double *modelScores, const 
             }
         }
     }
+    free(changes);
+}
+
+/* scorer.score(rl) of one query, labels given through the ranking idx (MetricScorer subclasses) */
+static double query_score(ro_trainer *t, int32_t metric, const float *labels, const int32_t *idx, int32_t n, int32_t k,
+                          int32_t key, int32_t *rel, int32_t *scratch)
+{
+    if (metric == RO_METRIC_NDCG) {
+        for (int32_t i = 0; i < n; i++) rel[i] = (int32_t)labels[idx[i]];
+        return ndcg_score_ranked(t, rel, n, k, key, scratch);
+    }
+    float *lr = (float *)malloc(sizeof(float) * (size_t)(n + 1));
+    for (int32_t i = 0; i < n; i++) lr[i] = labels[idx[i]];
+    double r;
+    if (metric == RO_METRIC_DCG) r = dcg_score_ranked(lr, n, k);
+    else if (metric == RO_METRIC_MAP) r = ap_score_ranked(lr, n);
+    else r = err_score_ranked(lr, n, k);
+    free(lr);
+    return r;
+}
+
+void ro_query_lambdas_metric(int32_t metric, const double *scores, const float *labels, int32_t n, int32_t k,
+                             double *lambda, double *weight)
+{
+    disc_reserve(n + 2);
+    int32_t *buf = (int32_t *)malloc(sizeof(int32_t) * (size_t)(4 * n + 4));
+    memset(lambda, 0, sizeof(double) * (size_t)n);
+    memset(weight, 0, sizeof(double) * (size_t)n);
+    query_lambdas(NULL, scores, labels, 0, n, k, -1, metric == RO_METRIC_NDCG ? -1.0 : -2.0 - metric, lambda, weight,
+                  buf, buf + n, buf + 3 * n + 2);
+    free(buf);
+}
+
+double ro_query_score(int32_t metric, const double *scores, const float *labels, int32_t n, int32_t k)
+{
+    disc_reserve(n + 2);
+    int32_t *buf = (int32_t *)malloc(sizeof(int32_t) * (size_t)(4 * n + 4));
+    int32_t *idx = buf, *tmp = buf + n, *rel = buf + 3 * n + 2;
+    sort_idx(scores, 0, n, 0, idx, tmp, tmp + n);
+    const double r = query_score(NULL, metric, labels, idx, n, k, -1, rel, tmp);
+    free(buf);
+    return r;
 }
 
 void ro_query_lambdas(const double *scores, const float *labels, int32_t n, int32_t k, double ideal_override,
@@ -716,6 +867,10 @@ static void lambda_chunk(void *c_, int32_t qs, int32_t qe, int32_t worker)
 void ro_compute_lambdas(ro_trainer *t)
 {
     const int32_t N = (int32_t)t->tr.n;
+    if (t->p.ranker == RO_RANKER_MART) {                          /* MART.computePseudoResponses, learning/tree/MART.java:47-51 */
+        for (int32_t i = 0; i < N; i++) t->pseudoResponses[i] = t->tr.labels[i] - t->modelScores[i];
+        return;
+    }
     for (int32_t i = 0; i < N; i++) { t->pseudoResponses[i] = 0.0F; t->weights[i] = 0; }  /* :332-333 */
     lam_ctx c = { t };
     pool_run(&t->pool, t->tr.q, lambda_chunk, &c);
@@ -1016,8 +1171,7 @@ static float model_score(ro_trainer *t, const dataset_t *d, const double *scores
         const int32_t cur = d->qoff[q], n = d->qoff[q + 1] - cur;
         int32_t *idx = buf, *tmp = buf + n, *rel = buf + 3 * n + 2;
         sort_idx(scores, cur, n, 0, idx, tmp, tmp + n);           /* rank(), :432-440 */
-        for (int32_t i = 0; i < n; i++) rel[i] = (int32_t)d->labels[idx[i]];
-        const double sc = ndcg_score_ranked(t, rel, n, t->p.metric_k, query_key(d, q, keybase), tmp);
+        const double sc = query_score(t, t->p.metric, d->labels, idx, n, t->p.metric_k, query_key(d, q, keybase), rel, tmp);
         s = (float)((double)s + sc);                              /* float s; s += double  :479 */
     }
     free(buf);
@@ -1062,7 +1216,8 @@ int ro_round(ro_trainer *t, ro_tree *out, float *train_metric, float *valid_metr
             s1 = (float)((double)s1 + t->pseudoResponses[k]);
             s2 = (float)((double)s2 + t->weights[k]);
         }
-        if (s2 == 0) s->avgLabel = 0; else s->avgLabel = (double)(s1 / s2);
+        if (t->p.ranker == RO_RANKER_MART) s->avgLabel = (double)(s1 / s->n);   /* MART.updateTreeOutput :54-65: float / int */
+        else if (s2 == 0) s->avgLabel = 0; else s->avgLabel = (double)(s1 / s2);
     }
     /* score update  :203-210 */
     for (int32_t i = 0; i < nl; i++) {
@@ -1142,8 +1297,7 @@ static double final_score(ro_trainer *t, const dataset_t *d, const float *X, int
         const int32_t cur = d->qoff[q], n = d->qoff[q + 1] - cur;
         int32_t *idx = buf, *tmp = buf + n, *rel = buf + 3 * n + 2;
         sort_idx(sc, cur, n, 0, idx, tmp, tmp + n);
-        for (int32_t i = 0; i < n; i++) rel[i] = (int32_t)d->labels[idx[i]];
-        score += ndcg_score_ranked(t, rel, n, t->p.metric_k, query_key(d, q, keybase), tmp);
+        score += query_score(t, t->p.metric, d->labels, idx, n, t->p.metric_k, query_key(d, q, keybase), rel, tmp);
     }
     free(buf); free(sc); free(ev);
     return score / d->q;

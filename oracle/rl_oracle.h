@@ -34,7 +34,11 @@ typedef struct {
     float   learning_rate;    /* LambdaMART.learningRate     :38 (float!) */
     int32_t metric_k;         /* NDCG@k, DCGScorer.k         metric/DCGScorer.java:21 */
     int32_t n_threads;        /* MyThreadPool size           utilities/MyThreadPool.java:42 */
+    int32_t ranker;           /* RO_RANKER_*: 6 = LambdaMART (learning/tree/LambdaMART.java), 0 = MART (learning/tree/MART.java) */
+    int32_t metric;           /* RO_METRIC_*: the train / validation metric (-metric2t), metric/MetricScorerFactory.java:24-30 */
 } ro_params;
+enum { RO_RANKER_MART = 0, RO_RANKER_LAMBDAMART = 6 };
+enum { RO_METRIC_NDCG = 0, RO_METRIC_DCG = 1, RO_METRIC_MAP = 2, RO_METRIC_ERR = 3 };
 
 /* One regression tree, nodes in pre-order (root = 0, left subtree first), which
  * is also the order of Split.leaves() (learning/tree/Split.java:100-113). */
@@ -119,6 +123,11 @@ void   ro_sort_desc(const double *scores, int32_t n, int32_t *idx);
 /* lambdas/weights of one query: NDCGScorer.swapChange + LambdaMART.java:361-396 */
 void   ro_query_lambdas(const double *scores, const float *labels, int32_t n, int32_t k,
                         double ideal_override /* <0: compute */, double *lambda, double *weight);
+/* the same for any metric (RO_METRIC_*): swapChange of metric/{NDCG,DCG,AP,ERR}Scorer.java + LambdaMART.java:361-396 */
+void   ro_query_lambdas_metric(int32_t metric, const double *scores, const float *labels, int32_t n, int32_t k,
+                               double *lambda, double *weight);
+/* MetricScorer.score(RankList) of the list ranked by `scores` (stable descending) */
+double ro_query_score(int32_t metric, const double *scores, const float *labels, int32_t n, int32_t k);
 double ro_query_ndcg(const double *scores, const float *labels, int32_t n, int32_t k,
                      double ideal_override);
 /* float running sum  LambdaMART.java:401-408 */

@@ -104,7 +104,8 @@ class NDCG:
         self.k = k
         self.ideal_gains = {}  # NDCGScorer.java:32
 
-    def score(self, rel_ranked, qid):  # NDCGScorer.java:103-129
+    def score(self, lab_ranked, qid):  # NDCGScorer.java:103-129
+        rel_ranked = [int(l) for l in lab_ranked]  # MetricScorer.getRelevanceLabels :54-60
         n = len(rel_ranked)
         if n == 0:
             return 0.0
@@ -123,7 +124,8 @@ class NDCG:
             dcg += gain(rel_ranked[i]) * discount(i)
         return dcg / ideal
 
-    def swap_change(self, rel_ranked, qid):  # NDCGScorer.java:132-160
+    def swap_change(self, lab_ranked, qid):  # NDCGScorer.java:132-160
+        rel_ranked = [int(l) for l in lab_ranked]
         n = len(rel_ranked)
         size = self.k if n > self.k else n
         ideal = self.ideal_gains.get(qid)
@@ -138,6 +140,118 @@ class NDCG:
                     changes[j][i] = v
         return changes
 
+
+class DCG:  # metric/DCGScorer.java
+    def __init__(self, k=10):
+        self.k = k
+
+    def score(self, lab_ranked, qid):  # :58-71
+        n = len(lab_ranked)
+        if n == 0:
+            return 0.0
+        size = n if (self.k > n or self.k <= 0) else self.k
+        dcg = 0.0
+        for i in range(size):
+            dcg += gain(int(lab_ranked[i])) * discount(i)
+        return dcg
+
+    def swap_change(self, lab_ranked, qid):  # :74-90
+        n = len(lab_ranked)
+        rel = [int(l) for l in lab_ranked]
+        size = self.k if n > self.k else n
+        changes = [[0.0] * n for _ in range(n)]
+        for i in range(size):
+            for j in range(i + 1, n):
+                v = (discount(i) - discount(j)) * (gain(rel[i]) - gain(rel[j]))
+                changes[i][j] = changes[j][i] = v
+        return changes
+
+
+class MAP:  # metric/APScorer.java  (k = 0 unless "MAP@k"; the score ignores k)
+    def __init__(self, k=0):
+        self.k = k
+
+    def score(self, lab_ranked, qid):  # :73-100
+        ap, count = 0.0, 0
+        for i, l in enumerate(lab_ranked):
+            if l > 0.0:
+                count += 1
+                ap += count / (i + 1)
+        return 0.0 if count == 0 else ap / count
+
+    def swap_change(self, lab_ranked, qid):  # :108-162
+        n = len(lab_ranked)
+        labels, rel_count, count = [], [], 0
+        for l in lab_ranked:
+            labels.append(1 if l > 0 else 0)
+            count += labels[-1]
+            rel_count.append(count)
+        changes = [[0.0] * n for _ in range(n)]
+        if count == 0:
+            return changes
+        for i in range(n - 1):
+            for j in range(i + 1, n):
+                change = 0.0
+                if labels[i] != labels[j]:
+                    diff = labels[j] - labels[i]
+                    change += float((rel_count[i] + diff) * labels[j] - rel_count[i] * labels[i]) / (i + 1)
+                    for k in range(i + 1, j):
+                        if labels[k] > 0:
+                            change += float(diff) / (k + 1)
+                    change += float(-rel_count[j] * diff) / (j + 1)
+                changes[i][j] = changes[j][i] = change / count
+        return changes
+
+
+class ERR:  # metric/ERRScorer.java
+    MAX = 16.0
+
+    def __init__(self, k=10):
+        self.k = k
+
+    def R(self, rel):  # :71-73
+        return ((1 << rel) - 1) / self.MAX
+
+    def score(self, lab_ranked, qid):  # :45-64
+        n = len(lab_ranked)
+        size = n if (self.k > n or self.k <= 0) else self.k
+        s, p = 0.0, 1.0
+        for i in range(1, size + 1):
+            r = self.R(int(lab_ranked[i - 1]))
+            s += p * r / i
+            p *= (1.0 - r)
+        return s
+
+    def swap_change(self, lab_ranked, qid):  # :76-115 (arrays beyond `size` stay 0; np is p * (1 - R) with p *= np)
+        n = len(lab_ranked)
+        size = self.k if n > self.k else n
+        labels, R, npp = [0] * n, [0.0] * n, [0.0] * n
+        p = 1.0
+        for i in range(size):
+            labels[i] = int(lab_ranked[i])
+            R[i] = self.R(labels[i])
+            npp[i] = p * (1.0 - R[i])
+            p *= npp[i]
+        changes = [[0.0] * n for _ in range(n)]
+        for i in range(size):
+            base = 1 if i == 0 else npp[i - 1]
+            v1 = 1.0 / (i + 1) * base
+            for j in range(i + 1, n):
+                if labels[i] == labels[j]:
+                    change = 0.0
+                else:
+                    change = v1 * (R[j] - R[i])
+                    p = base * (R[i] - R[j])
+                    for k in range(i + 1, j):
+                        change += p * R[k] / (1 + k)
+                        p *= 1.0 - R[k]
+                    with np.errstate(all="ignore"):
+                        change += float((np.float64(npp[j - 1]) * (1.0 - R[j]) * R[i] / np.float64(1.0 - R[i]) - npp[j - 1] * R[j]) / (j + 1))
+                changes[i][j] = changes[j][i] = change
+        return changes
+
+
+SCORERS = {"NDCG": NDCG, "DCG": DCG, "MAP": MAP, "ERR": ERR}
 
 # ----------------------------------------------------------------------------
 # learning/tree/*
@@ -181,7 +295,7 @@ class Split:  # Split.java:22-38
 
 class LambdaMART:
     def __init__(self, X, labels, qoff, n_trees=5, n_leaves=10, lr=0.1, n_threshold=256, mls=1, k=10,
-                 early_stop=100, feature_ids=None, qids=None):
+                 early_stop=100, feature_ids=None, qids=None, metric="NDCG", ranker="LAMBDAMART"):
         self.X = np.asarray(X, dtype=F32)
         self.N, self.F = self.X.shape
         self.labels = np.asarray(labels, dtype=F32)
@@ -189,7 +303,8 @@ class LambdaMART:
         self.Q = len(self.qoff) - 1
         self.n_trees, self.n_leaves, self.lr = n_trees, n_leaves, F32(lr)
         self.n_threshold, self.mls, self.early_stop = n_threshold, mls, early_stop
-        self.scorer = NDCG(k)
+        self.scorer = SCORERS[metric](k)
+        self.ranker = ranker
         self.features = list(feature_ids) if feature_ids is not None else list(range(1, self.F + 1))
         self.qids = list(qids) if qids is not None else ["q%d" % i for i in range(self.Q)]
         self.valid = None
@@ -254,6 +369,10 @@ class LambdaMART:
     # ---- computePseudoResponses  LambdaMART.java:331-396 ----
     def compute_lambdas(self):
         N = self.N
+        if self.ranker == "MART":  # learning/tree/MART.java:47-51 (weights stay untouched)
+            self.pseudo = [float(self.labels[i]) - self.model_scores[i] for i in range(N)]
+            self.weights = [0.0] * N
+            return
         self.pseudo = [0.0] * N
         self.weights = [0.0] * N
         cutoff = self.scorer.k
@@ -262,8 +381,8 @@ class LambdaMART:
             n = end - cur
             local = self.model_scores[cur:end]
             idx = [cur + i for i in stable_desc(local)]
-            rel = [int(self.labels[i]) for i in idx]
-            changes = self.scorer.swap_change(rel, self.qids[q])
+            lab = [float(self.labels[i]) for i in idx]
+            changes = self.scorer.swap_change(lab, self.qids[q])
             for j in range(n):
                 mj = idx[j]
                 for k in range(n):
@@ -395,8 +514,8 @@ class LambdaMART:
         for q in range(Q):
             cur, end = qoff[q], qoff[q + 1]
             order = stable_desc(scores[cur:end])
-            rel = [int(labels[cur + i]) for i in order]
-            s = F32(float(s) + self.scorer.score(rel, qids[q]))
+            lab = [float(labels[cur + i]) for i in order]
+            s = F32(float(s) + self.scorer.score(lab, qids[q]))
         return F32(s / F32(Q))
 
     def round(self):  # one iteration of LambdaMART.java:180-251
@@ -413,7 +532,10 @@ class LambdaMART:
             for k in lf.samples:
                 s1 = F32(float(s1) + self.pseudo[k])
                 s2 = F32(float(s2) + self.weights[k])
-            lf.output = 0.0 if s2 == 0 else float(F32(s1 / s2))
+            if self.ranker == "MART":  # MART.java:54-65: float sum / int count
+                lf.output = float(F32(s1 / F32(len(lf.samples))))
+            else:
+                lf.output = 0.0 if s2 == 0 else float(F32(s1 / s2))
         for lf in leaves:  # :203-210
             for k in lf.samples:
                 self.model_scores[k] += float(self.lr) * lf.output
@@ -450,7 +572,7 @@ class LambdaMART:
         for q in range(self.Q):
             cur, end = self.qoff[q], self.qoff[q + 1]
             order = stable_desc(sc[cur:end])
-            total += self.scorer.score([int(self.labels[cur + i]) for i in order], self.qids[q])
+            total += self.scorer.score([float(self.labels[cur + i]) for i in order], self.qids[q])
         return total / self.Q
 
 

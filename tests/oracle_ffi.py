@@ -13,7 +13,11 @@ _SO = os.path.join(_ORACLE_DIR, "librl_oracle.so")
 class RoParams(C.Structure):
     _fields_ = [("n_trees", C.c_int32), ("n_leaves", C.c_int32), ("n_threshold", C.c_int32),
                 ("min_leaf_support", C.c_int32), ("early_stop", C.c_int32), ("learning_rate", C.c_float),
-                ("metric_k", C.c_int32), ("n_threads", C.c_int32)]
+                ("metric_k", C.c_int32), ("n_threads", C.c_int32), ("ranker", C.c_int32), ("metric", C.c_int32)]
+
+
+RANKER = dict(MART=0, LAMBDAMART=6)
+METRIC = dict(NDCG=0, DCG=1, MAP=2, ERR=3)
 
 
 class RoTree(C.Structure):
@@ -82,6 +86,9 @@ def lib():
                                        C.c_void_p]
         L.ro_query_ndcg.restype = C.c_double
         L.ro_query_ndcg.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double]
+        L.ro_query_lambdas_metric.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.ro_query_score.restype = C.c_double
+        L.ro_query_score.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         L.ro_float_chain.restype = C.c_float
         L.ro_float_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         _lib = L
@@ -116,14 +123,15 @@ class Tree:
 
 class Oracle:
     def __init__(self, X, labels, qoff, n_trees=10, n_leaves=10, lr=0.1, n_threshold=256, mls=1, k=10,
-                 early_stop=100, n_threads=1, feature_ids=None, qkey=None, max_nodes=None):
+                 early_stop=100, n_threads=1, feature_ids=None, qkey=None, max_nodes=None, ranker="LAMBDAMART",
+                 metric="NDCG"):
         self.L = lib()
         self.X = np.ascontiguousarray(X, dtype=np.float32)
         self.labels = np.ascontiguousarray(labels, dtype=np.float32)
         self.qoff = np.ascontiguousarray(qoff, dtype=np.int32)
         self.N, self.F = self.X.shape
         self.Q = len(self.qoff) - 1
-        self.p = RoParams(n_trees, n_leaves, n_threshold, mls, early_stop, lr, k, n_threads)
+        self.p = RoParams(n_trees, n_leaves, n_threshold, mls, early_stop, lr, k, n_threads, RANKER[ranker], METRIC[metric])
         fid = None if feature_ids is None else np.ascontiguousarray(feature_ids, dtype=np.int32)
         qk = None if qkey is None else np.ascontiguousarray(qkey, dtype=np.int32)
         self._keep = (fid, qk)
@@ -244,6 +252,21 @@ def query_lambdas(scores, labels, k=10, ideal=-1.0):
     w = np.zeros(len(s))
     lib().ro_query_lambdas(s.ctypes.data, l.ctypes.data, len(s), k, ideal, lam.ctypes.data, w.ctypes.data)
     return lam, w
+
+
+def query_lambdas_metric(metric, scores, labels, k):
+    s = np.ascontiguousarray(scores, np.float64)
+    l = np.ascontiguousarray(labels, np.float32)
+    lam = np.zeros(len(s))
+    w = np.zeros(len(s))
+    lib().ro_query_lambdas_metric(METRIC[metric], s.ctypes.data, l.ctypes.data, len(s), k, lam.ctypes.data, w.ctypes.data)
+    return lam, w
+
+
+def query_score(metric, scores, labels, k):
+    s = np.ascontiguousarray(scores, np.float64)
+    l = np.ascontiguousarray(labels, np.float32)
+    return lib().ro_query_score(METRIC[metric], s.ctypes.data, l.ctypes.data, len(s), k)
 
 
 def query_ndcg(scores, labels, k=10, ideal=-1.0):
