@@ -54,7 +54,11 @@ enum {
     RL_ERR_COMM = -6         /* RCCL failure */
 };
 
-enum { RL_METRIC_NDCG = 0 };            /* metric/NDCGScorer.java (others: SURVEY.md 8f "next") */
+/* train / validation metric (-metric2t): metric/{NDCG,DCG,AP,ERR}Scorer.java.  P, RR and BEST are not built for
+ * training (RL_ERR_UNSUPPORTED); the host side can still report them on ranked lists. */
+enum { RL_METRIC_NDCG = 0, RL_METRIC_DCG = 1, RL_METRIC_MAP = 2, RL_METRIC_ERR = 3 };
+/* ranker: the indices of eval/Evaluator.java:69-73 */
+enum { RL_RANKER_MART = 0, RL_RANKER_LAMBDAMART = 6 };
 
 enum {                                  /* rl_params.flags */
     RL_FLAG_FAST_LEAF = 1,              /* leaf sums as exact-f64 tree sums instead of emulating the Java float
@@ -75,10 +79,12 @@ typedef struct {
     int32_t min_leaf_support;   /* LambdaMART.minLeafSupport    default 1    */
     int32_t early_stop_rounds;  /* LambdaMART.nRoundToStopEarly default 100  */
     float   learning_rate;      /* LambdaMART.learningRate      default 0.1F (a Java float) */
-    int32_t metric;             /* RL_METRIC_NDCG */
-    int32_t metric_k;           /* NDCG@k, default 10 (metric/DCGScorer.java:21) */
+    int32_t metric;             /* RL_METRIC_* */
+    int32_t metric_k;           /* the scorer's k: default 10 for NDCG / DCG / ERR (metric/DCGScorer.java:21,
+                                   metric/ERRScorer.java:28), 0 for MAP (metric/APScorer.java:37-39) */
     int32_t device;             /* HIP device ordinal */
     int32_t flags;              /* RL_FLAG_* */
+    int32_t ranker;             /* RL_RANKER_LAMBDAMART (default) or RL_RANKER_MART (learning/tree/MART.java:47-65) */
 } rl_params;
 
 /* One regression tree: nodes in pre-order (root 0, left subtree first) == Split.leaves() order

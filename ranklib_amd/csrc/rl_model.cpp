@@ -73,7 +73,7 @@ static void write_node(const HostTree &t, int n, const std::string &indent, std:
 std::string model_to_text(const ModelHeader &h, const std::vector<HostTree> &trees)
 {
     std::string o;
-    o += "## LambdaMART\n";                                                          // LambdaMART.java:292
+    o += std::string("## ") + h.name + "\n";                                                        // LambdaMART.java:292
     o += "## No. of trees = " + std::to_string(h.n_trees) + "\n";
     o += "## No. of leaves = " + std::to_string(h.n_leaves) + "\n";
     o += "## No. of threshold candidates = " + std::to_string(h.n_threshold) + "\n";

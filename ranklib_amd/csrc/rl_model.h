@@ -23,6 +23,7 @@ struct ModelHeader {                    // the "## ..." lines of LambdaMART.mode
     int n_trees, n_leaves, n_threshold;
     float learning_rate;
     int early_stop;
+    const char *name = "LambdaMART";     // Ranker.name(): "LambdaMART" or "MART" (learning/tree/MART.java:41-44)
 };
 
 // java.lang.Float.toString / Double.toString renderings (shortest decimal that round-trips, Java's

@@ -50,6 +50,7 @@ struct DataSet {
     float *d_labels = nullptr; int32_t *d_qoff = nullptr; double *d_ideal0 = nullptr, *d_ideal1 = nullptr;
     double *d_scores = nullptr, *d_ndcg = nullptr;
     double *d_ss = nullptr; float *d_sl = nullptr; int32_t *d_srel = nullptr, *d_sidx = nullptr, *d_docq = nullptr;   // ranked order (training set only)
+    int32_t *d_aux_i = nullptr; double *d_aux_a = nullptr, *d_aux_b = nullptr;   // swapChange tables of MAP / ERR in ranked order
     int32_t *d_qsmall = nullptr, *d_qbig = nullptr; int32_t n_small = 0, n_big = 0; bool all_small = false;
     int32_t *d_q128 = nullptr, *d_qlong = nullptr; int32_t n_q128 = 0, n_qlong = 0;   // split at kLambdaFusedSmall
     int32_t maxq = 0;
@@ -288,7 +289,7 @@ static int launch_rank(rl_trainer *t, DataSet &d, const double *scores, double *
 {
     RankArgs a{scores, d.d_labels, d.d_qoff, d.d_ideal1, t->ctx.disc,
                ranked ? d.d_ss : nullptr, ranked ? d.d_sl : nullptr, ranked ? d.d_srel : nullptr, ranked ? d.d_sidx : nullptr,
-               out, t->p.metric_k};
+               out, t->p.metric_k, t->p.metric, ranked ? d.d_aux_i : nullptr, ranked ? d.d_aux_a : nullptr, ranked ? d.d_aux_b : nullptr};
     if (d.n_small > 0)
         hipLaunchKernelGGL(k_rank_wave, dim3((d.n_small + 3) / 4), dim3(kThreads), 4 * kLambdaWaveCap * 12, t->stream, a,
                            d.all_small ? (const int *)nullptr : d.d_qsmall, d.n_small);
@@ -330,12 +331,18 @@ static int enqueue_round(rl_trainer *t)
     const int m = t->round;
     // round scalars
     RL_HIP(hipMemsetAsync(&c.st->maxabs_bits, 0, sizeof(unsigned long long) + sizeof(long long), s));
-    {   // K1 lambdas: pair terms in parallel, then ordered accumulation (ranked order comes from the previous
+    if (c.mart) {    // MART: residuals instead of lambdas (weights stay 0)
+        ScopedTiming tm(t, RL_KERNEL_LAMBDA, (double)c.N * 20.0);
+        hipLaunchKernelGGL(k_mart_residual, dim3(std::min(2048, (c.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                           c.labels, (const double *)c.scores, c.lambda, c.N, &c.st->maxabs_bits);
+    } else {   // K1 lambdas: pair terms in parallel, then ordered accumulation (ranked order comes from the previous
         // round's k_rank_* / from rl_init for round 0)
         ScopedTiming tm(t, RL_KERNEL_LAMBDA, (double)c.N * 28.0);
-        LamArgs g{t->tr.d_ss, t->tr.d_sl, t->tr.d_srel, t->tr.d_sidx, c.qoff, t->tr.d_docq, m == 0 ? c.ideal0 : c.ideal1, c.disc,
-                  t->d_T, c.lambda, c.weight, &c.st->maxabs_bits, c.N, c.k, c.k};
-        if (c.k <= kLambdaFusedMaxK) {
+        const double *ideal = (c.metric == RL_METRIC_NDCG) ? (m == 0 ? c.ideal0 : c.ideal1) : nullptr;
+        LamArgs g{t->tr.d_ss, t->tr.d_sl, t->tr.d_srel, t->tr.d_sidx, c.qoff, t->tr.d_docq, ideal, c.disc,
+                  t->d_T, c.lambda, c.weight, &c.st->maxabs_bits, c.N, c.k, c.k, c.metric, t->p.metric_k,
+                  t->tr.d_aux_i, t->tr.d_aux_a, t->tr.d_aux_b};
+        if (t->d_T == nullptr) {
             const size_t l128 = (size_t)c.k * 128 * 16 + (size_t)c.k * 24 + 128 * 4;
             const size_t l256 = (size_t)c.k * 256 * 16 + (size_t)c.k * 24 + 256 * 4;
             if (t->tr.n_q128 > 0) hipLaunchKernelGGL(k_lambda_fused<128>, dim3(t->tr.n_q128), dim3(128), l128, s, g, (const int *)t->tr.d_q128, t->tr.n_q128);
@@ -530,14 +537,18 @@ void rl_params_default(rl_params *p)
     if (!p) return;
     p->n_trees = 1000; p->n_leaves = 10; p->n_threshold = 256; p->min_leaf_support = 1; p->early_stop_rounds = 100;
     p->learning_rate = 0.1F; p->metric = RL_METRIC_NDCG; p->metric_k = 10; p->device = 0; p->flags = 0;
+    p->ranker = RL_RANKER_LAMBDAMART;
 }
 
 int rl_create(const rl_params *p, rl_trainer **out)
 {
     if (!p || !out) return fail(RL_ERR_INVALID, "null argument");
     *out = nullptr;
-    if (p->metric != RL_METRIC_NDCG) return fail(RL_ERR_UNSUPPORTED, "only NDCG@k is built (SURVEY.md 8f)");
-    if (p->metric_k < 1) return fail(RL_ERR_UNSUPPORTED, "NDCG@k needs k >= 1");
+    if (p->metric < RL_METRIC_NDCG || p->metric > RL_METRIC_ERR)
+        return fail(RL_ERR_UNSUPPORTED, "train metric must be NDCG, DCG, MAP or ERR (P / RR / BEST are not built for training)");
+    if (p->metric == RL_METRIC_MAP ? p->metric_k < 0 : p->metric_k < 1) return fail(RL_ERR_UNSUPPORTED, "metric k out of range");
+    if (p->ranker != RL_RANKER_LAMBDAMART && p->ranker != RL_RANKER_MART)
+        return fail(RL_ERR_UNSUPPORTED, "ranker must be RL_RANKER_LAMBDAMART (6) or RL_RANKER_MART (0)");
     if (p->n_trees < 1) return fail(RL_ERR_INVALID, "n_trees must be >= 1");
     if (p->n_leaves == -1) return fail(RL_ERR_UNSUPPORTED, "unlimited leaves (-leaf -1) is not built yet");
     if (p->n_leaves < 1) return fail(RL_ERR_INVALID, "n_leaves must be >= 1");
@@ -642,7 +653,11 @@ int rl_init(rl_trainer *t)
     const int Npad = (N + 127) / 128 * 128;
     c.N = N; c.Npad = Npad; c.Q = t->tr.Q; c.F = F; c.L = t->p.n_leaves; c.MAXN = 2 * t->p.n_leaves - 1;
     c.NC = 4 * t->p.n_leaves + 2;     // node records: committed (2L-1) + prepared but never reached (see k_select)
-    c.mls = t->p.min_leaf_support; c.k = t->p.metric_k; c.lr = t->p.learning_rate;
+    c.mls = t->p.min_leaf_support; c.lr = t->p.learning_rate;
+    c.metric = t->p.metric; c.mart = (t->p.ranker == RL_RANKER_MART) ? 1 : 0;
+    // rows of a ranked list whose pairs the lambda loop visits (LambdaMART.java:375-377: j <= cutoff or k <= cutoff); for
+    // NDCG / DCG / ERR row `cutoff` itself only holds zero swap changes
+    c.k = (t->p.metric == RL_METRIC_MAP) ? t->p.metric_k + 1 : t->p.metric_k;
     c.rank = t->rank; c.n_ranks = t->n_ranks;
 
     // ---- K9: thresholds + bins on the device ----------------------------------------------------
@@ -850,8 +865,14 @@ int rl_init(rl_trainer *t)
         std::vector<int32_t> docq((size_t)N);
         for (int q = 0; q < d.Q; q++) for (int i = d.qoff[q]; i < d.qoff[q + 1]; i++) docq[i] = q;
         RL_HIP(hipMemcpy(d.d_docq, docq.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice));
-        if ((size_t)N * c.k * sizeof(double2) > ((size_t)16 << 30)) return fail(RL_ERR_UNSUPPORTED, "NDCG@k with this k needs more than 16 GiB of pair terms");
-        if (c.k > kLambdaFusedMaxK) RL_HIP(t->pool.alloc(&t->d_T, (size_t)N * c.k));
+        // the LDS-resident fused kernel serves NDCG / DCG with few rows; everything else goes through the pair-term matrix
+        const bool fused = !c.mart && (c.metric == RL_METRIC_NDCG || c.metric == RL_METRIC_DCG) && c.k <= kLambdaFusedMaxK;
+        if (!c.mart && !fused) {
+            if ((size_t)N * c.k * sizeof(double2) > ((size_t)16 << 30)) return fail(RL_ERR_UNSUPPORTED, "this metric cutoff needs more than 16 GiB of pair terms");
+            RL_HIP(t->pool.alloc(&t->d_T, (size_t)N * c.k));
+        }
+        if (c.metric == RL_METRIC_MAP) RL_HIP(t->pool.alloc(&d.d_aux_i, (size_t)N));
+        if (c.metric == RL_METRIC_ERR) { RL_HIP(t->pool.alloc(&d.d_aux_a, (size_t)N)); RL_HIP(t->pool.alloc(&d.d_aux_b, (size_t)N)); }
         RL_HIP(hipDeviceSynchronize());
         int rc = launch_rank(t, d, c.scores, d.d_ndcg, true);      // ranking of the all-zero start scores (file order)
         if (rc) return rc;
@@ -1022,7 +1043,8 @@ int rl_model_to_text(const rl_trainer *t, char *buf, int64_t cap, int64_t *neede
     if (t->synced_rounds < t->n_kept) return fail(RL_ERR_STATE, "rounds still in flight: call rl_sync first");
     std::vector<HostTree> trees((size_t)t->n_kept);
     for (int i = 0; i < t->n_kept; i++) { int rc = fetch_tree(t, i, trees[i]); if (rc) return rc; }
-    ModelHeader h{t->p.n_trees, t->p.n_leaves, t->p.n_threshold, t->p.learning_rate, t->p.early_stop_rounds};
+    ModelHeader h{t->p.n_trees, t->p.n_leaves, t->p.n_threshold, t->p.learning_rate, t->p.early_stop_rounds,
+                  t->p.ranker == RL_RANKER_MART ? "MART" : "LambdaMART"};
     const std::string s = model_to_text(h, trees);                // LambdaMART.model()  LambdaMART.java:290-301
     if (needed) *needed = (int64_t)s.size() + 1;
     if (buf && cap >= (int64_t)s.size() + 1) memcpy(buf, s.c_str(), s.size() + 1);

@@ -72,7 +72,7 @@ def main(argv=None):
     args = list(sys.argv[1:] if argv is None else argv)
     logging.basicConfig(level=logging.INFO, format="%(message)s")
     if not args:
-        print("Usage: -train <file> -ranker 6 [-metric2t NDCG@k] [-tree n] [-leaf n] [-shrinkage f] [-tc n] [-mls n] [-estop n] "
+        print("Usage: -train <file> -ranker 6|0 [-metric2t NDCG@k|DCG@k|MAP|ERR@k] [-tree n] [-leaf n] [-shrinkage f] [-tc n] [-mls n] [-estop n] "
               "[-validate f] [-test f] [-feature f] [-save model] | -load model [-test f] [-rank f -indri out] [-score out]")
         return 0
     trainFile = validationFile = testFile = featureDescriptionFile = savedModelFile = rankFile = indriRankingFile = scoreFile = modelFile = ""
@@ -109,17 +109,21 @@ def main(argv=None):
         elif a == "-mls": LambdaMART.minLeafSupport = int(nxt())
         elif a == "-estop": LambdaMART.nRoundToStopEarly = int(nxt())
         elif a == "-thread": nxt()                          # CPU thread pool of the reference: irrelevant here
+        elif a in ("-frate", "-srate", "-bag", "-round", "-epoch", "-tolerance", "-reg", "-r", "-i", "-norm", "-kcv", "-tvs", "-tts",
+                   "-layer", "-node", "-lr", "-noeq", "-max", "-rtype", "-l2"):
+            # parameters of the other rankers / of flows that are out of scope: parsed (the reference's own test passes
+            # -frate -bag -round -epoch to every ranker, test:eval/EvaluatorTest.java:207-220) and ignored
+            if a != "-noeq":
+                nxt()
         elif a == "-device": LambdaMART.device = int(nxt())
         else:
             raise RankLibError("Unknown command-line parameter: " + args[i])     # :369-371 (incl. the documented -silent)
         i += 1
     if not testMetric:
         testMetric = trainMetric                            # :379-381
-    if trainFile and rankerType != 6:
-        raise RankLibError("rlhip builds -ranker 6 (LambdaMART) only")
-    if not trainFile and trainMetric == "ERR@10":
-        trainMetric = testMetric = "NDCG@10"                # load / rank / score flows do not need the train metric
-    e = Evaluator(RankerType.LAMBDAMART, trainMetric, testMetric)
+    if trainFile and rankerType not in (0, 6):
+        raise RankLibError("rlhip builds -ranker 6 (LambdaMART) and -ranker 0 (MART) only")
+    e = Evaluator(RankerType(rankerType) if rankerType in (0, 6) else RankerType.LAMBDAMART, trainMetric, testMetric)
     if trainFile:
         e.evaluate(trainFile, validationFile or None, testFile or None, featureDescriptionFile or None, modelFile or None)
     elif savedModelFile:

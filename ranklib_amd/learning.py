@@ -23,6 +23,7 @@ import numpy as np
 
 from . import _native as N
 from ._native import RankLibError
+from .metric import TRAINABLE
 
 logger = logging.getLogger("ranklib_amd")
 
@@ -253,6 +254,7 @@ class LambdaMART(Ranker):
     nTreeLeaves = 10
     minLeafSupport = 1
     device = 0
+    _RANKER = "LAMBDAMART"
 
     def __init__(self, samples=None, features=None, scorer=None):
         super().__init__(samples, features, scorer)
@@ -264,15 +266,16 @@ class LambdaMART(Ranker):
 
     def init(self):                   # :68-166
         logger.info("Initializing... ")
-        if self.scorer is None or not self.scorer.name().startswith("NDCG@"):
-            raise RankLibError("rlhip: only NDCG@k is built for -ranker 6 (got %s)" % (self.scorer.name() if self.scorer else None))
+        metric = self.scorer.name().split("@")[0].upper() if self.scorer is not None else None
+        if metric not in TRAINABLE:
+            raise RankLibError("rlhip: the train metric must be one of NDCG, DCG, MAP, ERR (got %s)" % (self.scorer.name() if self.scorer else None))
         cls = type(self)
         self.impacts = np.zeros(len(self.features))
         X, lab, qoff, qkey = flatten(self.samples, self.features)
         nk = int(qkey.max()) + 1 if len(qkey) else 0
         t = N.Trainer(n_trees=cls.nTrees, n_leaves=cls.nTreeLeaves, learning_rate=cls.learningRate, n_threshold=cls.nThreshold,
                       min_leaf_support=cls.minLeafSupport, early_stop_rounds=cls.nRoundToStopEarly, metric_k=self.scorer.getK(),
-                      device=cls.device)
+                      device=cls.device, metric=metric, ranker=self._RANKER)
         t.set_train(X, lab, qoff, feature_ids=self.features, qkey=qkey)
         if self.validationSamples is not None:
             Xv, lv, qv, _ = flatten(self.validationSamples, self.features)
@@ -366,6 +369,18 @@ class LambdaMART(Ranker):
         logger.info("Stop early: %d rounds without performance gain on validation data", cls.nRoundToStopEarly)
 
 
+class MART(LambdaMART):
+    """learning/tree/MART.java: LambdaMART with residual pseudo-responses and mean leaf outputs ("Inherits *ALL*
+    parameters from LambdaMART": the class attributes above are shared, like the Java statics)."""
+    _RANKER = "MART"
+
+    def createNew(self):              # :36-39
+        return MART()
+
+    def name(self):                   # :41-44
+        return "MART"
+
+
 # ---------------------------------------------------------------------------------------------------------
 class RankerType(enum.Enum):          # learning/RankerType.java
     MART = 0
@@ -382,7 +397,7 @@ class RankerType(enum.Enum):          # learning/RankerType.java
 
 class RankerFactory:                  # learning/RankerFactory.java:36-118
     def __init__(self):
-        self.map = {"LAMBDAMART": "LAMBDAMART"}
+        self.map = {"LAMBDAMART": LambdaMART, "MART": MART}
 
     def createRanker(self, rtype, samples=None, features=None, scorer=None):
         if isinstance(rtype, str):
@@ -390,9 +405,9 @@ class RankerFactory:                  # learning/RankerFactory.java:36-118
                 rtype = RankerType[rtype]
             except KeyError:
                 raise RankLibError("Could find the class \"%s\" you specified. Make sure the jar library is in your classpath." % rtype)
-        if rtype is not RankerType.LAMBDAMART:
-            raise RankLibError("rlhip builds -ranker 6 (LambdaMART) only; %s is out of scope (SURVEY.md 8)" % rtype.name)
-        r = LambdaMART()
+        if rtype.name not in self.map:
+            raise RankLibError("rlhip builds -ranker 6 (LambdaMART) and -ranker 0 (MART) only; %s is out of scope (SURVEY.md 8)" % rtype.name)
+        r = self.map[rtype.name]()
         if samples is not None:
             r.setTrainingSet(samples)
             r.setFeatures(features)
@@ -403,8 +418,8 @@ class RankerFactory:                  # learning/RankerFactory.java:36-118
         first = fullText.split("\n", 1)[0]
         name = first.replace("## ", "").strip()
         if name.upper() not in self.map:
-            raise RankLibError("Model file does not start with '## LambdaMART' (got %r)" % first)
-        r = self.createRanker(RankerType.LAMBDAMART)
+            raise RankLibError("Model file does not start with '## LambdaMART' or '## MART' (got %r)" % first)
+        r = self.createRanker(RankerType[name.upper()])
         r.loadFromString(fullText)
         return r
 

@@ -1,7 +1,7 @@
-"""Host-side metric objects of the `-ranker 6` path: what `-metric2t NDCG@k` parses to and what Evaluator uses to
-report a ranked test list.  Mirrors metric/MetricScorer.java, metric/DCGScorer.java, metric/NDCGScorer.java and
-metric/MetricScorerFactory.java.  (The per-round training / validation metric is computed on the GPU; this
-class only scores already-ranked lists for the test-time report, as Evaluator does.)"""
+"""Host-side metric objects: what `-metric2t` / `-metric2T` parse to and what Evaluator uses to report a ranked test
+list.  Mirrors metric/MetricScorer.java, metric/{NDCG,DCG,AP,ERR,Precision,ReciprocalRank,BestAtK}Scorer.java and
+metric/MetricScorerFactory.java.  The per-round training / validation metric (NDCG, DCG, MAP or ERR) is computed on the
+GPU; these classes only score already-ranked lists for the test-time report, as Evaluator does."""
 import math
 
 from ._native import RankLibError
@@ -68,16 +68,146 @@ class NDCGScorer(MetricScorer):       # metric/NDCGScorer.java:29-175
         return dcg / ideal
 
 
+class DCGScorer(MetricScorer):        # metric/DCGScorer.java
+    def __init__(self, k=10):
+        super().__init__(k)
+
+    def copy(self):
+        return DCGScorer()
+
+    def name(self):
+        return "DCG@%d" % self.k
+
+    def scoreOne(self, rl):           # :58-71
+        n = rl.size()
+        if n == 0:
+            return 0.0
+        size = n if (self.k > n or self.k <= 0) else self.k
+        dcg = 0.0
+        for i in range(size):
+            dcg += gain(int(rl.get(i).getLabel())) * discount(i)
+        return dcg
+
+
+class APScorer(MetricScorer):         # metric/APScorer.java (K is ignored by score(); no external judgments)
+    def __init__(self):
+        super().__init__(0)
+
+    def copy(self):
+        return APScorer()
+
+    def name(self):
+        return "MAP"
+
+    def scoreOne(self, rl):           # :73-100
+        ap, count = 0.0, 0
+        for i in range(rl.size()):
+            if rl.get(i).getLabel() > 0.0:
+                count += 1
+                ap += count / (i + 1)
+        return 0.0 if count == 0 else ap / count
+
+
+class ERRScorer(MetricScorer):        # metric/ERRScorer.java
+    MAX = 16.0
+
+    def __init__(self, k=10):
+        super().__init__(k)
+
+    def copy(self):
+        return ERRScorer()
+
+    def name(self):
+        return "ERR@%d" % self.k
+
+    def scoreOne(self, rl):           # :45-64
+        n = rl.size()
+        size = n if (self.k > n or self.k <= 0) else self.k
+        s, p = 0.0, 1.0
+        for i in range(1, size + 1):
+            R = ((1 << int(rl.get(i - 1).getLabel())) - 1) / self.MAX
+            s += p * R / i
+            p *= (1.0 - R)
+        return s
+
+
+class PrecisionScorer(MetricScorer):  # metric/PrecisionScorer.java:28-40  (reporting only)
+    def __init__(self, k=10):
+        super().__init__(k)
+
+    def copy(self):
+        return PrecisionScorer()
+
+    def name(self):
+        return "P@%d" % self.k
+
+    def scoreOne(self, rl):
+        n = rl.size()
+        size = n if (self.k > n or self.k <= 0) else self.k
+        count = sum(1 for i in range(size) if rl.get(i).getLabel() > 0.0)
+        return count / size
+
+
+class ReciprocalRankScorer(MetricScorer):   # metric/ReciprocalRankScorer.java:21-35  (reporting only)
+    def __init__(self):
+        super().__init__(0)           # as written: k = 0 makes `size` 0, so plain "RR" always scores 0
+
+    def copy(self):
+        return ReciprocalRankScorer()
+
+    def name(self):
+        return "RR@%d" % self.k
+
+    def scoreOne(self, rl):
+        size = self.k if rl.size() > self.k else rl.size()
+        for i in range(size):
+            if rl.get(i).getLabel() > 0.0:
+                return float(_f32(1.0) / _f32(i + 1))       # 1.0f / firstRank
+        return 0.0
+
+
+class BestAtKScorer(MetricScorer):    # metric/BestAtKScorer.java:28-56  (reporting only)
+    def __init__(self, k=10):
+        super().__init__(k)
+
+    def copy(self):
+        return BestAtKScorer()
+
+    def name(self):
+        return "Best@%d" % self.k
+
+    def scoreOne(self, rl):
+        size = self.k - 1
+        if size < 0 or size > rl.size() - 1:
+            size = rl.size() - 1
+        mx, mi = -1.0, 0
+        for i in range(size + 1):
+            if mx < rl.get(i).getLabel():
+                mx, mi = rl.get(i).getLabel(), i
+        return float(rl.get(mi).getLabel())
+
+
+def _f32(x):
+    import numpy as np
+    return np.float32(x)
+
+
+TRAINABLE = ("NDCG", "DCG", "MAP", "ERR")     # metrics whose swapChange the GPU lambda kernels implement
+
+
 class MetricScorerFactory:            # metric/MetricScorerFactory.java:17-60
+    _map = {"MAP": APScorer, "NDCG": NDCGScorer, "DCG": DCGScorer, "P": PrecisionScorer, "RR": ReciprocalRankScorer,
+            "BEST": BestAtKScorer, "ERR": ERRScorer}
+
     def createScorer(self, metric, k=None):
         m, kk = metric, k
-        if "@" in metric:
+        if "@" in metric:             # e.g. "NDCG@5"  :43-57
             m, ks = metric.split("@", 1)
             kk = int(ks)
-        m = m.upper()
-        if m != "NDCG":
-            raise RankLibError("rlhip builds NDCG@k only (SURVEY.md 8f lists MAP / ERR / DCG as next); got %r" % metric)
-        s = NDCGScorer()
+        cls = self._map.get(m.upper())
+        if cls is None:
+            raise RankLibError("Unknown metric %r" % metric)
+        s = cls()
         if kk is not None:
             s.setK(kk)
         return s

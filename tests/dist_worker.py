@@ -18,12 +18,13 @@ def main():
     from ranklib_amd import synth
 
     out_path, n_docs, n_feat, kind, seed, leaves, rounds = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
+    ranker, metric, k = (sys.argv[8], sys.argv[9], int(sys.argv[10])) if len(sys.argv) > 10 else ("LAMBDAMART", "NDCG", 10)
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     X, lab, qoff = synth.make_dataset(n_docs, n_feat, kind, seed_offset=seed)
     Xs, ls, qs = D.shard(X, lab, qoff, rank, world)
     tr = D.TorchHostTransport()
-    g = N.Trainer(n_trees=rounds, n_leaves=leaves)
+    g = N.Trainer(n_trees=rounds, n_leaves=leaves, ranker=ranker, metric=metric, metric_k=k)
     g.set_train(Xs, ls, qs)
     g.dist_init_callback(rank, world, tr.allreduce, tr.allgather)
     g.init()

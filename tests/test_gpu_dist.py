@@ -20,9 +20,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def single(n_docs, n_feat, kind, seed, leaves, rounds, dist_mode=None):
+def single(n_docs, n_feat, kind, seed, leaves, rounds, dist_mode=None, ranker="LAMBDAMART", metric="NDCG", k=10):
     X, lab, qoff = synth.make_dataset(n_docs, n_feat, kind, seed_offset=seed)
-    g = N.Trainer(n_trees=rounds, n_leaves=leaves)
+    g = N.Trainer(n_trees=rounds, n_leaves=leaves, ranker=ranker, metric=metric, metric_k=k)
     g.set_train(X, lab, qoff)
     if dist_mode == "rccl1":
         g.dist_init(g.dist_unique_id(), 0, 1)
@@ -58,13 +58,14 @@ def test_one_rank_distributed_paths_equal_plain_path():
     same(ref, single(*CFG, dist_mode="rccl1"))     # RCCL transport (dlopen'ed librccl), 1-rank communicator
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_k_shards_equal_one_shard(world, tmp_path):
-    ref = single(*CFG)
+@pytest.mark.parametrize("world,ranker,metric,k", [(2, "LAMBDAMART", "NDCG", 10), (3, "LAMBDAMART", "NDCG", 10),
+                                                    (2, "MART", "NDCG", 10), (2, "LAMBDAMART", "MAP", 0), (3, "LAMBDAMART", "ERR", 10)])
+def test_k_shards_equal_one_shard(world, ranker, metric, k, tmp_path):
+    ref = single(*CFG, ranker=ranker, metric=metric, k=k)
     out = str(tmp_path / "dist.npz")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(29511 + world), os.path.join(ROOT, "tests", "dist_worker.py"), out] + [str(v) for v in CFG]
+           "--master-port", str(29511 + world), os.path.join(ROOT, "tests", "dist_worker.py"), out] + [str(v) for v in CFG] + [ranker, metric, str(k)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     z = np.load(out)

@@ -289,3 +289,35 @@ def test_ndcg_cutoffs_fused_and_general_lambda_paths(k):
         assert np.array_equal(g.array("WEIGHT").view(np.int64), o.weights().view(np.int64)), (k, r)
         assert_same_tree(to, tg, X, "k %d round %d" % (k, r))
         assert tmo == tmg
+
+
+# ---- MART and the other train metrics ----------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranker,metric,k,kind,seed", [
+    ("MART", "NDCG", 10, "ns", 0), ("MART", "ERR", 10, "mslr", 1),
+    ("LAMBDAMART", "DCG", 10, "ns", 2), ("LAMBDAMART", "DCG", 3, "mslr", 3),
+    ("LAMBDAMART", "MAP", 0, "ns", 4), ("LAMBDAMART", "MAP", 4, "mslr", 5),
+    ("LAMBDAMART", "ERR", 10, "ns", 6), ("LAMBDAMART", "ERR", 3, "mslr", 7), ("LAMBDAMART", "NDCG", 20, "mslr", 8)])
+def test_other_rankers_and_metrics_match_the_oracle(ranker, metric, k, kind, seed):
+    """lambdas / weights / scores / per-round metric bit for bit, trees equivalent (tree_equiv), final metric equal"""
+    n_docs = 3000 if kind == "ns" else 6000
+    X, lab, qoff = synth.make_dataset(n_docs, 12, kind, seed_offset=50 + seed)
+    rounds, leaves = 5, 8
+    o = O.Oracle(X, lab, qoff, n_trees=rounds, n_leaves=leaves, k=k, ranker=ranker, metric=metric, n_threads=4)
+    g = N.Trainer(n_trees=rounds, n_leaves=leaves, metric_k=k, metric=metric, ranker=ranker)
+    g.set_train(X, lab, qoff)
+    o.init(); g.init()
+    for m in range(rounds):
+        to, tmo, _, _ = o.round()
+        tg, tmg, _, _ = g.boost_round()
+        assert np.array_equal(g.array("LAMBDA"), o.lambdas()), "lambda mismatch in round %d" % m
+        if ranker != "MART":
+            assert np.array_equal(g.array("WEIGHT"), o.weights())
+        assert_equivalent(to, tg, X, ctx="round %d" % m)
+        assert np.array_equal(g.array("SCORE"), o.scores()), "scores mismatch in round %d" % m
+        assert np.float32(tmg) == np.float32(tmo)
+    so, _ = o.finish()
+    sg, _ = g.finish()
+    assert sg == so
+    text = g.model_text()
+    assert text.startswith("## %s\n" % ("MART" if ranker == "MART" else "LambdaMART"))

@@ -58,11 +58,22 @@ def test_metric_factory_and_ndcg_scorer():
     s = mf.createScorer("ndcg@5")
     assert s.name() == "NDCG@5" and s.getK() == 5
     assert mf.createScorer("NDCG").getK() == 10
+    m = mf.createScorer("map")
+    assert m.name() == "MAP" and m.getK() == 0                      # metric/APScorer.java:37-39
+    assert mf.createScorer("MAP@7").getK() == 7
+    assert mf.createScorer("ERR").name() == "ERR@10" and mf.createScorer("dcg@3").name() == "DCG@3"
+    assert mf.createScorer("P@5").name() == "P@5" and mf.createScorer("RR").getK() == 0 and mf.createScorer("best").name() == "Best@10"
     with pytest.raises(RankLibError):
-        mf.createScorer("MAP")
+        mf.createScorer("nope")
     rl = learning.RankList([learning.DataPoint("%d qid:q 1:0" % l) for l in (2, 0, 1)])
     d = [1.0, 1.0 / (np.log(3) / np.log(2)), 0.5]
     assert mf.createScorer("NDCG@10").score(rl) == (3 * d[0] + 0 * d[1] + 1 * d[2]) / 3.6309297535714573
+    assert mf.createScorer("DCG@2").score(rl) == 3 * d[0] + 0 * d[1]
+    assert mf.createScorer("MAP").score(rl) == (1.0 + 2.0 / 3.0) / 2
+    assert mf.createScorer("P@2").score(rl) == 0.5 and mf.createScorer("RR").score(rl) == 0.0 and mf.createScorer("RR@3").score(rl) == 1.0
+    assert mf.createScorer("Best@2").score(rl) == 2.0
+    R = [3 / 16.0, 0.0, 1 / 16.0]
+    assert mf.createScorer("ERR@10").score(rl) == R[0] / 1 + (1 - R[0]) * R[1] / 2 + (1 - R[0]) * (1 - R[1]) * R[2] / 3
 
 
 def test_cli_flag_quirks():
@@ -103,3 +114,27 @@ def test_reference_lambdamart_behaviour_through_the_cli(tmp_path):
     assert best_p == 1 and best_p < best_n
     rows = [l.split("\t") for l in open(sc)]
     assert len(rows) == 200 and rows[0][0] == "x" and rows[5][1] == "5"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rnum,header", [(6, "## LambdaMART"), (0, "## MART")])
+def test_reference_test_flow_verbatim(tmp_path, rnum, header):
+    """test:eval/EvaluatorTest.java:128-137 (testMART), :186-195 (testLambdaMART) -> testRanker :207-260, flag for flag:
+    `-metric2t map`, the other rankers' parameters passed along, default 1000 trees."""
+    data, model, run = (str(tmp_path / n) for n in ("data.txt", "model.txt", "run.txt"))
+    write_random_data(data)
+    evaluator.main(["-train", data, "-metric2t", "map", "-ranker", str(rnum), "-frate", "1.0", "-bag", "10", "-round", "10",
+                    "-epoch", "10", "-save", model])
+    evaluator.main(["-rank", data, "-load", model, "-indri", run])
+    assert open(model).read().startswith(header + "\n## No. of trees = 1000\n")
+    p_rank = n_rank = 2 ** 31 - 1
+    for line in open(run):
+        row = line.split()
+        assert row[1] == "Q0"
+        rank, score = int(row[3]), float(row[4])
+        assert np.isfinite(score) and rank > 0
+        if row[2].startswith("P"):
+            p_rank = min(rank, p_rank)
+        else:
+            n_rank = min(rank, n_rank)
+        assert p_rank < n_rank and p_rank == 1
