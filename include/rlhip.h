@@ -162,6 +162,11 @@ int  rl_model_features(const rl_model *m, int32_t *ids, int32_t cap, int32_t *n)
 /* X row-major [n][row_stride]; feature ID f is read from column f (column 0 unused, like DataPoint.fVals);
  * IDs >= row_stride read as 0 (the -missingZero behaviour). */
 int  rl_model_predict(rl_model *m, const float *X, int64_t n_docs, int32_t row_stride, float *out);
+/* The same on buffers that already live in the model's device memory (rows and scores are DEVICE pointers); the work is
+ * enqueued on `stream` (a hipStream_t, NULL = the default stream) and NOT synchronised.  This is the call a serving
+ * loop uses: Ensemble.eval for a batch of rows without the PCIe round trip (eval/Evaluator.java:1076-1094 does the
+ * same per DataPoint on the CPU). */
+int  rl_model_predict_device(rl_model *m, const float *dX, int64_t n_docs, int32_t row_stride, float *dOut, void *stream);
 
 /* ---- multi-GPU (one process per GPU; queries sharded across ranks) ---------- */
 #define RL_UNIQUE_ID_BYTES 128

@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "rl_set_train", "rl_set_validation", "rl_init", "rl_boost_round", "rl_boost_rounds_async", "rl_sync",
     "rl_finish", "rl_num_trees", "rl_get_tree", "rl_get_round_metrics", "rl_best_validation", "rl_predict",
     "rl_model_to_text", "rl_model_from_text", "rl_model_destroy", "rl_model_num_trees", "rl_model_features",
-    "rl_model_predict", "rl_dist_unique_id", "rl_dist_init", "rl_dist_init_callback", "rl_bin_stride", "rl_quant_exponent", "rl_get_array",
+    "rl_model_predict", "rl_model_predict_device", "rl_dist_unique_id", "rl_dist_init", "rl_dist_init_callback", "rl_bin_stride", "rl_quant_exponent", "rl_get_array",
     "rl_get_timing", "rl_reset_timing",
 ]
 
@@ -94,6 +94,7 @@ def lib():
     L.rl_model_num_trees.argtypes = [vp, C.POINTER(i32)]
     L.rl_model_features.argtypes = [vp, vp, i32, C.POINTER(i32)]
     L.rl_model_predict.argtypes = [vp, vp, i64, i32, vp]
+    L.rl_model_predict_device.argtypes = [vp, vp, i64, i32, vp, vp]
     L.rl_dist_unique_id.argtypes = [vp]
     L.rl_dist_init.argtypes = [vp, vp, i32, i32]
     L.rl_dist_init_callback.argtypes = [vp, i32, i32, HOST_ALLREDUCE, HOST_ALLGATHER, vp]
@@ -353,6 +354,11 @@ class Model:
         out = np.zeros(rows.shape[0], np.float32)
         check(lib().rl_model_predict(self.h, rows.ctypes.data, rows.shape[0], rows.shape[1], out.ctypes.data))
         return out
+
+    def predict_device(self, dX_ptr, n_docs, row_stride, dOut_ptr, stream=None):
+        """rows / scores are device pointers (e.g. torch tensors' data_ptr()); enqueued, not synchronised"""
+        check(lib().rl_model_predict_device(self.h, C.c_void_p(dX_ptr), n_docs, row_stride, C.c_void_p(dOut_ptr),
+                                            C.c_void_p(stream) if stream else None))
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:

@@ -1210,6 +1210,7 @@ struct rl_model {
     DevPool pool;
     EnsTree ens;
     float *d_w = nullptr;
+    unsigned long long *d_pack = nullptr;   // packed nodes for k_model_eval_tiled (null when the model does not fit the packing)
 };
 
 namespace rl {
@@ -1231,6 +1232,69 @@ __global__ __launch_bounds__(kThreads) void k_model_eval(const EnsTree e, const 
             s = (float)((double)s + (double)e.out[o + nd] * (double)w[t]);     // Ensemble.java:113
         }
         out[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K10: Ensemble.eval for many trees.  One block scores a tile of 256 documents against the
+// whole ensemble:
+//   * the tile's feature rows are transposed into LDS once, sX[column][doc]: a thread reads sX[c * 256 + tid], so the
+//     bank is tid % 32 whatever column the thread's path asks for -- conflict-free;
+//   * trees stream through LDS in tiles of kEvalTreeTile as packed 8-byte nodes
+//       bits 0..31 threshold (or leaf output) float bits | 32..47 column (0xFFFF = leaf) | 48..55 left | 56..63 right
+//   * a thread walks kEvalIlp trees at once (independent chains hide the LDS latency; a leaf is a fixed point of the
+//     step, so finished trees idle in place), then adds the outputs in tree order: s = (float)(s + out * weight)
+//     exactly as Ensemble.eval does (learning/tree/Ensemble.java:110-116).
+// Needs <= 256 nodes per tree and row_stride * 1 KiB + tile <= 160 KiB of LDS; otherwise k_model_eval runs.
+// ------------------------------------------------------------------------------------------------
+constexpr int kEvalDocs = 256, kEvalTreeTile = 16, kEvalIlp = 8;
+
+__global__ __launch_bounds__(kEvalDocs) void k_model_eval_tiled(const unsigned long long *nodes, const float *w, int MAXN, int nt,
+                                                                const float *X, int64_t n, int stride, float *out)
+{
+    extern __shared__ unsigned char ev_raw[];
+    float *sX = (float *)ev_raw;                                               // [stride][256]
+    unsigned long long *sT = (unsigned long long *)(sX + (size_t)stride * kEvalDocs);   // [kEvalTreeTile][MAXN]
+    const int tid = threadIdx.x;
+    for (int64_t tile = blockIdx.x; tile * kEvalDocs < n; tile += gridDim.x) {
+        const int64_t d0 = tile * kEvalDocs;
+        const int nd = (int)min((int64_t)kEvalDocs, n - d0);
+        __syncthreads();
+        const float *src = X + (size_t)d0 * stride;                            // the tile is one contiguous range of X
+        for (int e = tid; e < nd * stride; e += kEvalDocs) { const int doc = e / stride, c = e - doc * stride; sX[c * kEvalDocs + doc] = src[e]; }
+        float s = 0.f;
+        for (int t0 = 0; t0 < nt; t0 += kEvalTreeTile) {
+            const int tt = min(kEvalTreeTile, nt - t0);
+            __syncthreads();
+            for (int e = tid; e < tt * MAXN; e += kEvalDocs) sT[e] = nodes[(size_t)t0 * MAXN + e];
+            __syncthreads();
+            if (tid < nd) {
+                for (int g = 0; g < tt; g += kEvalIlp) {
+                    int base[kEvalIlp];
+                    unsigned long long v[kEvalIlp];
+#pragma unroll
+                    for (int u = 0; u < kEvalIlp; u++) { base[u] = min(g + u, tt - 1) * MAXN; v[u] = sT[base[u]]; }
+                    bool any = true;
+                    while (any) {
+                        any = false;
+#pragma unroll
+                        for (int u = 0; u < kEvalIlp; u++) {
+                            const unsigned c = (unsigned)(v[u] >> 32) & 0xffffu;
+                            if (c != 0xffffu) {                                  // Split.eval: value <= threshold goes left (Split.java:118)
+                                const float x = (c < (unsigned)stride) ? sX[c * kEvalDocs + tid] : 0.f;   // -missingZero
+                                const int nx = (x <= __uint_as_float((unsigned)v[u])) ? (int)((v[u] >> 48) & 0xff) : (int)(v[u] >> 56);
+                                v[u] = sT[base[u] + nx];
+                                any = true;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < kEvalIlp; u++)
+                        if (g + u < tt) s = (float)((double)s + (double)__uint_as_float((unsigned)v[u]) * (double)w[t0 + g + u]);   // Ensemble.java:113
+                }
+            }
+        }
+        if (tid < nd) out[d0 + tid] = s;
     }
 }
 }  // namespace rl
@@ -1272,6 +1336,26 @@ int rl_model_from_text(const char *text, int32_t device, rl_model **out)
     RL_HIP(hipMemcpy(m->ens.thr, th.data(), en * 4, hipMemcpyHostToDevice));
     RL_HIP(hipMemcpy(m->ens.out, ou.data(), en * 4, hipMemcpyHostToDevice));
     RL_HIP(hipMemcpy(m->d_w, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    {   // packed nodes (see k_model_eval_tiled)
+        bool ok = m->maxn <= 256 && nt > 0;
+        for (int32_t f : m->features) ok = ok && f >= 0 && f < 0xffff;
+        if (ok) {
+            std::vector<unsigned long long> pk(en, 0xffffull << 32);
+            for (size_t i = 0; i < nt; i++) {
+                const HostTree &t = m->trees[i];
+                for (int j = 0; j < t.n_nodes; j++) {
+                    const bool leaf = t.feature[j] == -1;
+                    uint32_t bits; const float fv = leaf ? t.output[j] : t.threshold[j];
+                    memcpy(&bits, &fv, 4);
+                    pk[i * m->maxn + j] = (unsigned long long)bits | ((unsigned long long)(leaf ? 0xffffu : (unsigned)t.feature[j]) << 32) |
+                                          ((unsigned long long)(leaf ? 0 : (unsigned)t.left[j]) << 48) | ((unsigned long long)(leaf ? 0 : (unsigned)t.right[j]) << 56);
+                }
+            }
+            RL_HIP(m->pool.alloc(&m->d_pack, en));
+            RL_HIP(hipMemcpy(m->d_pack, pk.data(), en * 8, hipMemcpyHostToDevice));
+            RL_HIP(hipFuncSetAttribute((const void *)k_model_eval_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
+    }
     *out = m.release();
     return RL_OK;
 }
@@ -1298,6 +1382,22 @@ int rl_model_features(const rl_model *m, int32_t *ids, int32_t cap, int32_t *n)
     return RL_OK;
 }
 
+static int model_eval_launch(rl_model *m, const float *dX, int64_t n_docs, int32_t row_stride, float *dO, hipStream_t s)
+{
+    const size_t lds = (size_t)row_stride * kEvalDocs * 4 + (size_t)kEvalTreeTile * m->maxn * 8;
+    static const bool force_generic = getenv("RLHIP_EVAL_GENERIC") != nullptr;       // cross-checks in the tests
+    if (m->d_pack && lds <= (size_t)160 * 1024 && !force_generic) {
+        const int64_t tiles = (n_docs + kEvalDocs - 1) / kEvalDocs;
+        hipLaunchKernelGGL(k_model_eval_tiled, dim3((unsigned)std::min<int64_t>(tiles, 256 * 64)), dim3(kEvalDocs), lds, s,
+                           (const unsigned long long *)m->d_pack, (const float *)m->d_w, m->maxn, (int)m->trees.size(), dX, n_docs, row_stride, dO);
+    } else {
+        hipLaunchKernelGGL(k_model_eval, dim3((unsigned)std::min<int64_t>(8192, (n_docs + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, m->ens,
+                           (const float *)m->d_w, m->maxn, (int)m->trees.size(), dX, n_docs, row_stride, dO);
+    }
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
 int rl_model_predict(rl_model *m, const float *X, int64_t n_docs, int32_t row_stride, float *out)
 {
     if (!m) return fail(RL_ERR_INVALID, "null model");
@@ -1308,13 +1408,19 @@ int rl_model_predict(rl_model *m, const float *X, int64_t n_docs, int32_t row_st
     RL_HIP(hipMalloc((void **)&dX, (size_t)n_docs * row_stride * sizeof(float)));
     RL_HIP(hipMalloc((void **)&dO, (size_t)n_docs * sizeof(float)));
     RL_HIP(hipMemcpy(dX, X, (size_t)n_docs * row_stride * sizeof(float), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_model_eval, dim3((unsigned)std::min<int64_t>(8192, (n_docs + kThreads - 1) / kThreads)), dim3(kThreads), 0, 0, m->ens,
-                       (const float *)m->d_w, m->maxn, (int)m->trees.size(), (const float *)dX, n_docs, row_stride, dO);
-    RL_HIP(hipGetLastError());
-    RL_HIP(hipDeviceSynchronize());
-    RL_HIP(hipMemcpy(out, dO, (size_t)n_docs * sizeof(float), hipMemcpyDeviceToHost));
+    int rc = model_eval_launch(m, dX, n_docs, row_stride, dO, 0);
+    if (rc == RL_OK) { RL_HIP(hipDeviceSynchronize()); RL_HIP(hipMemcpy(out, dO, (size_t)n_docs * sizeof(float), hipMemcpyDeviceToHost)); }
     (void)hipFree(dX); (void)hipFree(dO);
-    return RL_OK;
+    return rc;
+}
+
+int rl_model_predict_device(rl_model *m, const float *dX, int64_t n_docs, int32_t row_stride, float *dOut, void *stream)
+{
+    if (!m) return fail(RL_ERR_INVALID, "null model");
+    if (!dX || !dOut || n_docs < 0 || row_stride < 1) return fail(RL_ERR_INVALID, "bad argument");
+    if (n_docs == 0) return RL_OK;
+    RL_HIP(hipSetDevice(m->device));
+    return model_eval_launch(m, dX, n_docs, row_stride, dOut, (hipStream_t)stream);
 }
 
 }  // extern "C"

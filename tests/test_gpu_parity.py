@@ -321,3 +321,50 @@ def test_other_rankers_and_metrics_match_the_oracle(ranker, metric, k, kind, see
     assert sg == so
     text = g.model_text()
     assert text.startswith("## %s\n" % ("MART" if ranker == "MART" else "LambdaMART"))
+
+
+# ---- Ensemble.eval at scale (LDS-tiled kernel, packed nodes) ------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_feat,leaves,rounds", [(136, 31, 37), (20, 10, 16), (12, 150, 3)])
+def test_tiled_ensemble_eval_equals_oracle(n_feat, leaves, rounds):
+    """trees > one LDS tile, partial document tiles, 137-column rows (140 KiB of LDS), -missingZero columns, and a model
+    with more than 256 nodes per tree (falls back to the generic kernel): scores bit for bit"""
+    import torch
+    X, lab, qoff = make(5000, n_feat, "mslr", 21)
+    o, g = pair(X, lab, qoff, n_trees=rounds, n_leaves=leaves)
+    o.init(); g.init()
+    for _ in range(rounds):
+        o.round(); g.boost_round(want_tree=False)
+    g.finish()
+    m = N.Model(g.model_text())
+    assert m.num_trees() == rounds
+    n = 1337
+    want = o.predict(X[:n])
+    rows = np.zeros((n, n_feat + 1), np.float32)
+    rows[:, 1:] = X[:n]
+    assert np.array_equal(m.predict_rows(rows).view(np.uint32), want.view(np.uint32))
+    # rows that stop before the last feature ids: missing columns read as 0 (-missingZero).  Zeroed columns are rows the
+    # trees were not grown on, where a tie-resolved split may legitimately route differently from the oracle's (DESIGN.md
+    # section 1), so the reference here is a direct evaluation of the SAME trees: Split.eval + Ensemble.eval in numpy.
+    cut = n_feat // 2
+    trees = [g.get_tree(i).trimmed() for i in range(rounds)]
+    lr = np.float64(np.float32(0.1))
+    ref = np.zeros(n, np.float32)
+    for i in range(n):
+        acc = np.float32(0)
+        for t in trees:
+            nd = 0
+            while t["feature"][nd] != -1:
+                f = int(t["feature"][nd])
+                v = rows[i, f] if f <= cut else np.float32(0)
+                nd = int(t["left"][nd]) if v <= t["threshold"][nd] else int(t["right"][nd])
+            acc = np.float32(np.float64(acc) + np.float64(t["output"][nd]) * lr)
+        ref[i] = acc
+    assert np.array_equal(m.predict_rows(rows[:, :cut + 1].copy()).view(np.uint32), ref.view(np.uint32))
+    # device-resident rows (the serving call)
+    dX = torch.from_numpy(rows).cuda()
+    dO = torch.zeros(n, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    m.predict_device(dX.data_ptr(), n, rows.shape[1], dO.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(dO.cpu().numpy().view(np.uint32), want.view(np.uint32))
