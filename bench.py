@@ -43,6 +43,100 @@ def pmc_traffic(shape, world):
         return None
 
 
+def bench_infer(args):
+    """--workload infer (BASELINE.json configs[4] shape): Ensemble.eval of a 10 000-tree model on rows resident
+    in HBM.  Trees: `--infer-train-rounds` real boosting rounds on MSLR-shaped data, tiled to `--trees`; rows: generated on
+    the device with the same column kinds as ranklib_amd.synth.  A step scores the whole batch once."""
+    import numpy as np
+    import torch
+    from ranklib_amd import _native as N
+    from ranklib_amd import synth
+    torch.cuda.set_device(0)
+    F, L = 136, 31
+    X, lab, qoff = synth.make_dataset(200000, F, "mslr")
+    g = N.Trainer(n_trees=args.infer_train_rounds, n_leaves=L)
+    g.set_train(X, lab, qoff)
+    g.init()
+    g.boost_rounds_async(args.infer_train_rounds)
+    g.sync()
+    g.finish()
+    trees = [g.get_tree(i).trimmed() for i in range(args.infer_train_rounds)]
+    text = g.model_text()
+    head, body = text.split("<ensemble>\n", 1)
+    blocks = body.rsplit("</ensemble>", 1)[0].split("\t</tree>\n")[:-1]
+    reps = (args.trees + len(blocks) - 1) // len(blocks)
+    tiled = []
+    for r in range(reps):
+        for b in blocks:
+            if len(tiled) < args.trees:
+                tiled.append(b.split(">", 1)[1])        # drop the <tree id=.. weight=..> opening, re-numbered below
+    text = head + "<ensemble>\n" + "".join("\t<tree id=\"%d\" weight=\"0.1\">%s\t</tree>\n" % (i + 1, t) for i, t in enumerate(tiled)) + "</ensemble>\n"
+    t0 = time.time()
+    m = N.Model(text)
+    t_load = time.time() - t0
+    nt = m.num_trees()
+    # mean path length on the training distribution from the per-node training counts
+    visits = float(np.mean([t["count"][t["feature"] != -1].sum() / t["count"][0] for t in trees]))
+    n = args.docs
+    stride = F + 1
+    gen = torch.Generator(device="cuda").manual_seed(20240601)
+    dX = torch.empty((n, stride), dtype=torch.float32, device="cuda")
+    chunk = 1 << 20
+    for a in range(0, n, chunk):
+        b = min(n, a + chunk)
+        u = torch.rand((b - a, stride), generator=gen, device="cuda")
+        k = torch.arange(stride, device="cuda") % 4                   # column kinds of synth.make_dataset (feature id f = column f)
+        cnt = torch.floor(u * 21.0)
+        heavy = torch.exp(4.0 * u)
+        sparse = torch.where(torch.rand((b - a, stride), generator=gen, device="cuda") < 0.7, torch.zeros_like(u), u)
+        dX[a:b] = torch.where(k == 1, cnt, torch.where(k == 2, u, torch.where(k == 3, heavy, sparse)))
+        dX[a:b, 0] = 0
+    dO = torch.empty(n, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        m.predict_device(dX.data_ptr(), n, stride, dO.data_ptr())
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        m.predict_device(dX.data_ptr(), n, stride, dO.data_ptr())
+    e1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = e0.elapsed_time(e1) / args.steps
+    docs_per_s = n * args.steps / elapsed
+    out = {
+        "metric": "documents scored/sec (Ensemble.eval, %d trees x %d leaves)" % (nt, L), "value": docs_per_s, "unit": "docs/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 compares, f32 score chain (as Ensemble.eval)",
+        "data": "synthetic",
+        "config": {"workload": "c4-shape inference: %d documents x %d features resident in HBM, %d trees (%d trained rounds tiled), "
+                               "31 leaves" % (n, F, nt, args.infer_train_rounds),
+                   "mean_node_visits_per_tree": visits, "node_visits_per_s": docs_per_s * nt * visits,
+                   "model_parse_seconds": round(t_load, 2)},
+        "roofline": {"kernel": "rl::k_model_eval_tiled", "bound": "hbm", "achieved": n * stride * 4.0 / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": n * stride * 4.0 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "note": "HBM is not the limiter here: every row is read once and visited %d x %.1f times in LDS; the kernel is bound by "
+                             "LDS / VALU issue (DESIGN.md 4.8), node_visits_per_s is the figure of merit" % (nt, visits)},
+    }
+    if args.cpu_rounds > 0:
+        import oracle_ffi as O
+        threads = args.cpu_threads or (os.cpu_count() or 1)
+        ns = min(n, max(threads * 64, int(2.0e9 / (nt * max(visits, 1.0)) / 4)))      # ~ a few seconds of CPU work
+        rows = dX[:ns].cpu().numpy()
+        all_trees = [trees[i % len(trees)] for i in range(nt)]
+        tc = time.perf_counter()
+        ref = O.eval_flat_model(all_trees, rows, n_threads=threads)
+        t_cpu = time.perf_counter() - tc
+        same = bool(np.array_equal(ref.view(np.uint32), dO[:ns].cpu().numpy().view(np.uint32)))
+        out["cpu_baseline"] = {"value": ns / t_cpu, "unit": "docs/s", "cores": threads, "kind": "port",
+                               "sample": "the first %d rows of the same batch, same %d trees, C restatement of Ensemble.eval with the rows split "
+                                         "over %d threads; scores identical to the GPU's: %s" % (ns, nt, threads, same)}
+        out["speedup_vs_cpu_baseline"] = docs_per_s / (ns / t_cpu)
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -52,7 +146,15 @@ def main():
     ap.add_argument("--cpu-rounds", type=int, default=8, help="rounds timed for the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores (RankLib's default -thread)")
     ap.add_argument("--no-timing", action="store_true", help="do not record HIP events around the dominant kernel")
+    ap.add_argument("--workload", default="train", help="train (default, the BASELINE.json metric) | infer (configs[4]: Ensemble.eval)")
+    ap.add_argument("--trees", type=int, default=10000, help="infer: trees in the scored model")
+    ap.add_argument("--docs", type=int, default=10000000, help="infer: rows per step (54.8 GB at the 100 M of configs[4])")
+    ap.add_argument("--infer-train-rounds", type=int, default=100)
     args = ap.parse_args()
+    if args.workload == "infer":
+        if not any(a.startswith("--steps") for a in sys.argv):
+            args.steps, args.warmup = 3, 1
+        return bench_infer(args)
 
     import numpy as np
     import torch

@@ -1283,6 +1283,47 @@ void ro_predict(const ro_trainer *t, const float *X, int64_t n_docs, float *out)
     free(fid2col);
 }
 
+/* Ensemble.eval (learning/tree/Ensemble.java:110-116, Split.eval learning/tree/Split.java:115-125) of a flat model
+ * (n_trees x maxn nodes, feature < 0 = leaf; feature f is read from column f of the row, columns >= stride read 0) on
+ * n rows, documents split over n_threads like a caller scoring lists in parallel would.  CPU baseline of config c4. */
+typedef struct { int32_t nt, maxn; const int32_t *feature, *left, *right; const float *thr, *outv, *w; const float *X; int64_t n;
+                 int32_t stride; float *res; int32_t n_threads, id; } evm_arg;
+static void *evm_main(void *a_)
+{
+    evm_arg *a = (evm_arg *)a_;
+    const int64_t per = (a->n + a->n_threads - 1) / a->n_threads, i0 = per * a->id, i1 = (i0 + per < a->n) ? i0 + per : a->n;
+    for (int64_t i = i0; i < i1; i++) {
+        const float *row = a->X + i * a->stride;
+        float s = 0;
+        for (int32_t t = 0; t < a->nt; t++) {
+            const size_t o = (size_t)t * a->maxn;
+            int32_t nd = 0;
+            while (a->feature[o + nd] >= 0) {
+                const int32_t f = a->feature[o + nd];
+                const float v = f < a->stride ? row[f] : 0.0f;
+                nd = (v <= a->thr[o + nd]) ? a->left[o + nd] : a->right[o + nd];
+            }
+            s = (float)((double)s + (double)a->outv[o + nd] * (double)a->w[t]);
+        }
+        a->res[i] = s;
+    }
+    return NULL;
+}
+void ro_eval_flat_model(int32_t n_trees, int32_t maxn, const int32_t *feature, const float *thr, const int32_t *left,
+                        const int32_t *right, const float *outv, const float *weight, const float *X, int64_t n,
+                        int32_t stride, int32_t n_threads, float *res)
+{
+    if (n_threads < 1) n_threads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    evm_arg *args = (evm_arg *)malloc(sizeof(evm_arg) * (size_t)n_threads);
+    for (int32_t k = 0; k < n_threads; k++) {
+        args[k] = (evm_arg){ n_trees, maxn, feature, left, right, thr, outv, weight, X, n, stride, res, n_threads, k };
+        pthread_create(&th[k], NULL, evm_main, &args[k]);
+    }
+    for (int32_t k = 0; k < n_threads; k++) pthread_join(th[k], NULL);
+    free(th); free(args);
+}
+
 /* scorer.score(rank(samples))  LambdaMART.java:259, Ranker.java:88-103,
  * MetricScorer.java:46-52 (double mean). Needs the raw rows again. */
 static double final_score(ro_trainer *t, const dataset_t *d, const float *X, int32_t keybase)

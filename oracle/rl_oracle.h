@@ -115,6 +115,12 @@ void ro_hist_update_only(ro_trainer *t);
 /* Ensemble.eval on arbitrary rows (float accumulation in tree order). */
 void ro_predict(const ro_trainer *t, const float *X, int64_t n_docs, float *out);
 
+/* Ensemble.eval of a flat model (n_trees x maxn node arrays, feature < 0 = leaf, feature f read from column f, columns
+ * >= stride read 0) on n rows with n_threads threads: the CPU baseline of the inference configuration (c4). */
+void ro_eval_flat_model(int32_t n_trees, int32_t maxn, const int32_t *feature, const float *thr, const int32_t *left,
+                        const int32_t *right, const float *outv, const float *weight, const float *X, int64_t n,
+                        int32_t stride, int32_t n_threads, float *res);
+
 /* Stand-alone pieces for known-answer tests */
 double ro_exp(double x);                       /* the exp used for rho (fdlibm e_exp restatement) */
 double ro_discount(int32_t i);                 /* metric/DCGScorer.java:26 */

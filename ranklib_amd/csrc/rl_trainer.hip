@@ -1211,6 +1211,7 @@ struct rl_model {
     EnsTree ens;
     float *d_w = nullptr;
     unsigned long long *d_pack = nullptr;   // packed nodes for k_model_eval_tiled (null when the model does not fit the packing)
+    int32_t maxcol = 0;                     // largest column any node reads
 };
 
 namespace rl {
@@ -1236,65 +1237,96 @@ __global__ __launch_bounds__(kThreads) void k_model_eval(const EnsTree e, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K10: Ensemble.eval for many trees.  One block scores a tile of 256 documents against the
-// whole ensemble:
-//   * the tile's feature rows are transposed into LDS once, sX[column][doc]: a thread reads sX[c * 256 + tid], so the
-//     bank is tid % 32 whatever column the thread's path asks for -- conflict-free;
-//   * trees stream through LDS in tiles of kEvalTreeTile as packed 8-byte nodes
-//       bits 0..31 threshold (or leaf output) float bits | 32..47 column (0xFFFF = leaf) | 48..55 left | 56..63 right
-//   * a thread walks kEvalIlp trees at once (independent chains hide the LDS latency; a leaf is a fixed point of the
-//     step, so finished trees idle in place), then adds the outputs in tree order: s = (float)(s + out * weight)
-//     exactly as Ensemble.eval does (learning/tree/Ensemble.java:110-116).
-// Needs <= 256 nodes per tree and row_stride * 1 KiB + tile <= 160 KiB of LDS; otherwise k_model_eval runs.
+// K10: Ensemble.eval for many trees.  One block scores a tile of kEvalDocs documents against
+// the whole ensemble:
+//   * the tile's feature rows are transposed into LDS once, sX[column][doc] (columns the rows do not have are zero:
+//     -missingZero): a lane reads sX[c * kEvalDocs + doc], so the bank is doc % 32 whatever column the lane's path asks
+//     for -- conflict-free;
+//   * trees stream through LDS in tiles of kEvalTreeTile as packed 8-byte nodes, children adjacent (right = left + 1):
+//       bits 0..31 threshold (or leaf output) float bits | 32..47 byte offset of the column in sX (0xFFFF = leaf)
+//       | 48..63 byte offset of the left child in the tree
+//     so a step is: load node, load value, compare, add -- 7 VALU + 2 LDS instructions;
+//   * wavefront p of the block walks trees [p*kEvalIlp, (p+1)*kEvalIlp) of the tile for all documents, kEvalIlp
+//     independent chains per lane (a leaf is a fixed point of the step, so finished trees idle in place), and leaves the
+//     leaf outputs in LDS; wavefront 0 then adds them in tree order, s = (float)(s + out * weight), exactly as
+//     Ensemble.eval does (learning/tree/Ensemble.java:110-116).  Splitting the TREES of a tile over the wavefronts
+//     (instead of giving every wavefront its own documents) keeps the LDS copy of a document shared by four
+//     wavefronts: 8 wavefronts per CU instead of 4 -- the kernel is latency-bound otherwise;
+//   * the next tile of trees is fetched into registers while the current one is walked.
+// Needs: column offsets and child offsets that fit 16 bits, and the LDS budget; otherwise k_model_eval runs.
 // ------------------------------------------------------------------------------------------------
-constexpr int kEvalDocs = 256, kEvalTreeTile = 16, kEvalIlp = 8;
+constexpr int kEvalDocs = 64, kEvalParts = 4, kEvalIlp = 8, kEvalTreeTile = kEvalParts * kEvalIlp;
+constexpr int kEvalThreads = kEvalDocs * kEvalParts, kEvalPrefetch = 8;     // 8-byte words each thread prefetches per tile
 
-__global__ __launch_bounds__(kEvalDocs) void k_model_eval_tiled(const unsigned long long *nodes, const float *w, int MAXN, int nt,
-                                                                const float *X, int64_t n, int stride, float *out)
+static inline size_t eval_tiled_lds(int cols, int maxn)
+{
+    return (size_t)cols * kEvalDocs * 4 + (size_t)kEvalTreeTile * maxn * 8 + (size_t)kEvalTreeTile * kEvalDocs * 4 + kEvalTreeTile * 4;
+}
+
+// cols = max(row_stride, largest column any node reads + 1)
+__global__ __launch_bounds__(kEvalThreads) void k_model_eval_tiled(const unsigned long long *nodes, const float *w, int MAXN, int nt,
+                                                                   const float *X, int64_t n, int stride, int cols, float *out)
 {
     extern __shared__ unsigned char ev_raw[];
-    float *sX = (float *)ev_raw;                                               // [stride][256]
-    unsigned long long *sT = (unsigned long long *)(sX + (size_t)stride * kEvalDocs);   // [kEvalTreeTile][MAXN]
-    const int tid = threadIdx.x;
+    float *sX = (float *)ev_raw;                                               // [cols][kEvalDocs]
+    unsigned long long *sT = (unsigned long long *)(sX + (size_t)cols * kEvalDocs);   // [kEvalTreeTile][MAXN]
+    float *sO = (float *)(sT + (size_t)kEvalTreeTile * MAXN);                  // [kEvalTreeTile][kEvalDocs] leaf outputs
+    float *sW = sO + kEvalTreeTile * kEvalDocs;                                // [kEvalTreeTile] tree weights
+    const int tid = threadIdx.x, doc = tid & (kEvalDocs - 1), part = tid / kEvalDocs;
+    const int tile_words = kEvalTreeTile * MAXN;                               // <= kEvalThreads * kEvalPrefetch (checked by the host)
+    const unsigned char *sXb = (const unsigned char *)sX + doc * 4;
     for (int64_t tile = blockIdx.x; tile * kEvalDocs < n; tile += gridDim.x) {
         const int64_t d0 = tile * kEvalDocs;
         const int nd = (int)min((int64_t)kEvalDocs, n - d0);
         __syncthreads();
         const float *src = X + (size_t)d0 * stride;                            // the tile is one contiguous range of X
-        for (int e = tid; e < nd * stride; e += kEvalDocs) { const int doc = e / stride, c = e - doc * stride; sX[c * kEvalDocs + doc] = src[e]; }
+        for (int e = tid; e < nd * stride; e += kEvalThreads) { const int dd = e / stride, c = e - dd * stride; sX[c * kEvalDocs + dd] = src[e]; }
+        for (int e = tid; e < (cols - stride) * kEvalDocs; e += kEvalThreads) sX[stride * kEvalDocs + e] = 0.f;
         float s = 0.f;
+        unsigned long long pre[kEvalPrefetch];
+#pragma unroll
+        for (int u = 0; u < kEvalPrefetch; u++) { const int e = tid + u * kEvalThreads; pre[u] = (e < min(tile_words, nt * MAXN)) ? nodes[e] : 0ull; }
         for (int t0 = 0; t0 < nt; t0 += kEvalTreeTile) {
             const int tt = min(kEvalTreeTile, nt - t0);
             __syncthreads();
-            for (int e = tid; e < tt * MAXN; e += kEvalDocs) sT[e] = nodes[(size_t)t0 * MAXN + e];
+#pragma unroll
+            for (int u = 0; u < kEvalPrefetch; u++) { const int e = tid + u * kEvalThreads; if (e < tile_words) sT[e] = pre[u]; }
+            if (tid < tt) sW[tid] = w[t0 + tid];
             __syncthreads();
-            if (tid < nd) {
-                for (int g = 0; g < tt; g += kEvalIlp) {
-                    int base[kEvalIlp];
-                    unsigned long long v[kEvalIlp];
+            {   // next tile -> registers (in flight during the walk)
+                const size_t nb = (size_t)(t0 + kEvalTreeTile) * MAXN;
+                const long long left = (long long)nt * MAXN - (long long)nb;
 #pragma unroll
-                    for (int u = 0; u < kEvalIlp; u++) { base[u] = min(g + u, tt - 1) * MAXN; v[u] = sT[base[u]]; }
-                    bool any = true;
-                    while (any) {
-                        any = false;
+                for (int u = 0; u < kEvalPrefetch; u++) { const int e = tid + u * kEvalThreads; pre[u] = (e < tile_words && e < left) ? nodes[nb + e] : 0ull; }
+            }
+            const int g = part * kEvalIlp;
+            if (doc < nd && g < tt) {
+                const unsigned char *tb[kEvalIlp];
+                unsigned long long v[kEvalIlp];
 #pragma unroll
-                        for (int u = 0; u < kEvalIlp; u++) {
-                            const unsigned c = (unsigned)(v[u] >> 32) & 0xffffu;
-                            if (c != 0xffffu) {                                  // Split.eval: value <= threshold goes left (Split.java:118)
-                                const float x = (c < (unsigned)stride) ? sX[c * kEvalDocs + tid] : 0.f;   // -missingZero
-                                const int nx = (x <= __uint_as_float((unsigned)v[u])) ? (int)((v[u] >> 48) & 0xff) : (int)(v[u] >> 56);
-                                v[u] = sT[base[u] + nx];
-                                any = true;
-                            }
+                for (int u = 0; u < kEvalIlp; u++) { tb[u] = (const unsigned char *)(sT + min(g + u, tt - 1) * MAXN); v[u] = *(const unsigned long long *)tb[u]; }
+                bool any = true;
+                while (any) {
+                    any = false;
+#pragma unroll
+                    for (int u = 0; u < kEvalIlp; u++) {
+                        const unsigned hi = (unsigned)(v[u] >> 32), co = hi & 0xffffu;
+                        if (co != 0xffffu) {                                   // Split.eval: value <= threshold goes left (Split.java:118)
+                            const float x = *(const float *)(sXb + co);
+                            const unsigned off = (hi >> 16) + ((x <= __uint_as_float((unsigned)v[u])) ? 0u : 8u);
+                            v[u] = *(const unsigned long long *)(tb[u] + off);
+                            any = true;
                         }
                     }
-#pragma unroll
-                    for (int u = 0; u < kEvalIlp; u++)
-                        if (g + u < tt) s = (float)((double)s + (double)__uint_as_float((unsigned)v[u]) * (double)w[t0 + g + u]);   // Ensemble.java:113
                 }
+#pragma unroll
+                for (int u = 0; u < kEvalIlp; u++) if (g + u < tt) sO[(g + u) * kEvalDocs + doc] = __uint_as_float((unsigned)v[u]);
             }
+            __syncthreads();
+            if (part == 0 && doc < nd)
+                for (int t = 0; t < tt; t++) s = (float)((double)s + (double)sO[t * kEvalDocs + doc] * (double)sW[t]);   // Ensemble.java:113
         }
-        if (tid < nd) out[d0 + tid] = s;
+        if (part == 0 && doc < nd) out[d0 + doc] = s;
     }
 }
 }  // namespace rl
@@ -1336,24 +1368,41 @@ int rl_model_from_text(const char *text, int32_t device, rl_model **out)
     RL_HIP(hipMemcpy(m->ens.thr, th.data(), en * 4, hipMemcpyHostToDevice));
     RL_HIP(hipMemcpy(m->ens.out, ou.data(), en * 4, hipMemcpyHostToDevice));
     RL_HIP(hipMemcpy(m->d_w, w.data(), w.size() * 4, hipMemcpyHostToDevice));
-    {   // packed nodes (see k_model_eval_tiled)
-        bool ok = m->maxn <= 256 && nt > 0;
-        for (int32_t f : m->features) ok = ok && f >= 0 && f < 0xffff;
+    {   // packed nodes (see k_model_eval_tiled): breadth-first renumbering puts siblings next to each other
+        int maxcol = 0;
+        for (int32_t f : m->features) maxcol = std::max(maxcol, f);
+        m->maxcol = maxcol;
+        bool ok = nt > 0 && (size_t)m->maxn * 8 < 0x10000 && (size_t)(maxcol + 1) * kEvalDocs * 4 < 0xffff &&
+                  (size_t)kEvalTreeTile * m->maxn <= (size_t)kEvalThreads * kEvalPrefetch;
+        for (int32_t f : m->features) ok = ok && f >= 0;
         if (ok) {
             std::vector<unsigned long long> pk(en, 0xffffull << 32);
-            for (size_t i = 0; i < nt; i++) {
+            std::vector<int> order, newid;
+            for (size_t i = 0; i < nt && ok; i++) {
                 const HostTree &t = m->trees[i];
-                for (int j = 0; j < t.n_nodes; j++) {
+                order.assign(1, 0); newid.assign(t.n_nodes, -1); newid[0] = 0;
+                for (size_t h = 0; h < order.size(); h++) {
+                    const int j = order[h];
+                    if (t.feature[j] == -1) continue;
+                    if (t.left[j] < 0 || t.right[j] < 0 || t.left[j] >= t.n_nodes || t.right[j] >= t.n_nodes) { ok = false; break; }
+                    newid[t.left[j]] = (int)order.size(); order.push_back(t.left[j]);
+                    newid[t.right[j]] = (int)order.size(); order.push_back(t.right[j]);
+                }
+                for (size_t h = 0; h < order.size() && ok; h++) {
+                    const int j = order[h];
                     const bool leaf = t.feature[j] == -1;
                     uint32_t bits; const float fv = leaf ? t.output[j] : t.threshold[j];
                     memcpy(&bits, &fv, 4);
-                    pk[i * m->maxn + j] = (unsigned long long)bits | ((unsigned long long)(leaf ? 0xffffu : (unsigned)t.feature[j]) << 32) |
-                                          ((unsigned long long)(leaf ? 0 : (unsigned)t.left[j]) << 48) | ((unsigned long long)(leaf ? 0 : (unsigned)t.right[j]) << 56);
+                    const unsigned long long co = leaf ? 0xffffull : (unsigned long long)t.feature[j] * kEvalDocs * 4;
+                    const unsigned long long lo = leaf ? 0ull : (unsigned long long)newid[t.left[j]] * 8;
+                    pk[i * m->maxn + h] = (unsigned long long)bits | (co << 32) | (lo << 48);
                 }
             }
-            RL_HIP(m->pool.alloc(&m->d_pack, en));
-            RL_HIP(hipMemcpy(m->d_pack, pk.data(), en * 8, hipMemcpyHostToDevice));
-            RL_HIP(hipFuncSetAttribute((const void *)k_model_eval_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            if (ok) {
+                RL_HIP(m->pool.alloc(&m->d_pack, en));
+                RL_HIP(hipMemcpy(m->d_pack, pk.data(), en * 8, hipMemcpyHostToDevice));
+                RL_HIP(hipFuncSetAttribute((const void *)k_model_eval_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            }
         }
     }
     *out = m.release();
@@ -1384,12 +1433,13 @@ int rl_model_features(const rl_model *m, int32_t *ids, int32_t cap, int32_t *n)
 
 static int model_eval_launch(rl_model *m, const float *dX, int64_t n_docs, int32_t row_stride, float *dO, hipStream_t s)
 {
-    const size_t lds = (size_t)row_stride * kEvalDocs * 4 + (size_t)kEvalTreeTile * m->maxn * 8;
+    const int cols = std::max(row_stride, m->maxcol + 1);
+    const size_t lds = eval_tiled_lds(cols, m->maxn);
     static const bool force_generic = getenv("RLHIP_EVAL_GENERIC") != nullptr;       // cross-checks in the tests
     if (m->d_pack && lds <= (size_t)160 * 1024 && !force_generic) {
         const int64_t tiles = (n_docs + kEvalDocs - 1) / kEvalDocs;
-        hipLaunchKernelGGL(k_model_eval_tiled, dim3((unsigned)std::min<int64_t>(tiles, 256 * 64)), dim3(kEvalDocs), lds, s,
-                           (const unsigned long long *)m->d_pack, (const float *)m->d_w, m->maxn, (int)m->trees.size(), dX, n_docs, row_stride, dO);
+        hipLaunchKernelGGL(k_model_eval_tiled, dim3((unsigned)std::min<int64_t>(tiles, 256 * 256)), dim3(kEvalDocs * kEvalParts), lds, s,
+                           (const unsigned long long *)m->d_pack, (const float *)m->d_w, m->maxn, (int)m->trees.size(), dX, n_docs, row_stride, cols, dO);
     } else {
         hipLaunchKernelGGL(k_model_eval, dim3((unsigned)std::min<int64_t>(8192, (n_docs + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, m->ens,
                            (const float *)m->d_w, m->maxn, (int)m->trees.size(), dX, n_docs, row_stride, dO);

@@ -89,6 +89,7 @@ def lib():
         L.ro_query_lambdas_metric.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.ro_query_score.restype = C.c_double
         L.ro_query_score.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.ro_eval_flat_model.argtypes = [C.c_int32, C.c_int32] + [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
         L.ro_float_chain.restype = C.c_float
         L.ro_float_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         _lib = L
@@ -288,3 +289,20 @@ def float_chain(x, idx=None):
         return np.float32(lib().ro_float_chain(x.ctypes.data, None, len(x)))
     idx = np.ascontiguousarray(idx, np.int32)
     return np.float32(lib().ro_float_chain(x.ctypes.data, idx.ctypes.data, len(idx)))
+
+
+def eval_flat_model(trees, rows, n_threads=1, weight=0.1):
+    """trees: list of dicts (feature ids, threshold, left, right, output) in any node order with root 0; rows[:, f] = feature f"""
+    nt = len(trees)
+    maxn = max(len(t["feature"]) for t in trees)
+    feat = np.full((nt, maxn), -1, np.int32); left = np.zeros((nt, maxn), np.int32); right = np.zeros((nt, maxn), np.int32)
+    thr = np.zeros((nt, maxn), np.float32); outv = np.zeros((nt, maxn), np.float32)
+    for i, t in enumerate(trees):
+        n = len(t["feature"])
+        feat[i, :n] = t["feature"]; left[i, :n] = t["left"]; right[i, :n] = t["right"]; thr[i, :n] = t["threshold"]; outv[i, :n] = t["output"]
+    w = np.full(nt, weight, np.float32)
+    rows = np.ascontiguousarray(rows, np.float32)
+    res = np.zeros(rows.shape[0], np.float32)
+    lib().ro_eval_flat_model(nt, maxn, feat.ctypes.data, thr.ctypes.data, left.ctypes.data, right.ctypes.data, outv.ctypes.data,
+                             w.ctypes.data, rows.ctypes.data, rows.shape[0], rows.shape[1], n_threads, res.ctypes.data)
+    return res
