@@ -207,6 +207,9 @@ enum {
     RL_ARR_GROW_STATS = 15      /* int32[4] cumulative: growth steps run, nodes prepared (partition + child histograms),
                                    splits committed to trees, trees grown -- speculative best-first growth */
 };
+/* The device's two exp implementations (rho of learning/tree/LambdaMART.java:383) on n arguments: the branch-free one the
+ * lambda kernels use and the literal fdlibm e_exp transcription; both must equal StrictMath.exp bit for bit. */
+int rl_debug_exp(const double *x, int32_t n, double *out_fast, double *out_ref);
 int rl_bin_stride(const rl_trainer *t, int32_t *stride);
 int rl_quant_exponent(const rl_trainer *t, int32_t *e);   /* q = rint(lambda * 2^e) in the last round */
 int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes);

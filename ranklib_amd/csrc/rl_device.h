@@ -61,6 +61,38 @@ __device__ inline double exp_fdlibm(double x)
     return y * bits2d(0x0170000000000000ULL);
 }
 
+// The same function without data-dependent branches on the common range (|x| < 700): the three argument-reduction cases
+// of e_exp only differ in k (0, +-1, or round(x / ln2)); hi = x - k*ln2HI and lo = k*ln2LO are the same expressions in all
+// of them (k = +-1 and k = 0 multiply exactly), and the two final formulas share one division with a selected
+// denominator.  Lanes of a wavefront therefore run ONE instruction stream whatever their arguments are, and two calls can
+// be interleaved by the compiler.  Rare arguments (overflow / underflow / subnormal results / NaN) take exp_fdlibm.
+__device__ __forceinline__ double exp_fdlibm_bf(double x)
+{
+    const double LN2_HI = bits2d(0x3fe62e42fee00000ULL), LN2_LO = bits2d(0x3dea39ef35793c76ULL);
+    const double INV_LN2 = bits2d(0x3ff71547652b82feULL);
+    const double C1 = bits2d(0x3FC555555555553EULL), C2 = bits2d(0xBF66C16C16BEBD93ULL),
+                 C3 = bits2d(0x3F11566AAF25DE2CULL), C4 = bits2d(0xBEBBBD41C5D26BF1ULL),
+                 C5 = bits2d(0x3E66376972BEA4D0ULL);
+    const uint64_t ux = d2bits(x);
+    const uint32_t top = (uint32_t)(ux >> 32) & 0x7fffffffu;
+    if (top >= 0x4085E000u) return exp_fdlibm(x);                  // |x| >= 700: everything unusual lives here
+    const bool neg = (ux >> 63) != 0;
+    const bool small = !(top > 0x3fd62e42u);                        // |x| <= 0.5 ln2: k = 0
+    const bool mid = top < 0x3FF0A2B2u;                             // |x| < 1.5 ln2: k = +-1
+    const int kg = (int)(INV_LN2 * x + (neg ? -0.5 : 0.5));
+    const int k = small ? 0 : (mid ? (neg ? -1 : 1) : kg);
+    const double t = (double)k;
+    const double hi = x - t * LN2_HI;
+    const double lo = t * LN2_LO;
+    const double xr = hi - lo;                                      // == x when k == 0
+    const double tt = xr * xr;
+    const double c = xr - tt * (C1 + tt * (C2 + tt * (C3 + tt * (C4 + tt * C5))));
+    const double q = (xr * c) / (small ? (c - 2.0) : (2.0 - c));
+    const double y = small ? (1.0 - (q - xr)) : (1.0 - ((lo - q) - hi));
+    const double r = bits2d(d2bits(y) + ((uint64_t)(uint32_t)k << 52));       // k >= -1021 here (|x| < 700)
+    return (top < 0x3e300000u) ? (1.0 + x) : r;                     // |x| < 2^-28
+}
+
 // value * 2^-e of a 128-bit fixed-point integer, rounded ONCE to nearest-even.
 __device__ inline double fixed_to_double(i128 v, int e)
 {

@@ -1180,6 +1180,22 @@ int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes)
     return RL_OK;
 }
 
+int rl_debug_exp(const double *x, int32_t n, double *out_fast, double *out_ref)
+{
+    if (!x || !out_fast || !out_ref || n < 0) return fail(RL_ERR_INVALID, "bad argument");
+    if (n == 0) return RL_OK;
+    double *d = nullptr;
+    RL_HIP(hipMalloc((void **)&d, (size_t)n * 3 * sizeof(double)));
+    RL_HIP(hipMemcpy(d, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_exp_probe, dim3((n + 255) / 256), dim3(256), 0, 0, (const double *)d, n, d + n, d + 2 * (size_t)n);
+    RL_HIP(hipGetLastError());
+    RL_HIP(hipDeviceSynchronize());
+    RL_HIP(hipMemcpy(out_fast, d + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    RL_HIP(hipMemcpy(out_ref, d + 2 * (size_t)n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return RL_OK;
+}
+
 int rl_get_timing(rl_trainer *t, int32_t kernel, double *total_ms, int64_t *launches, double *alg_bytes)
 {
     if (check_trainer(t)) return RL_ERR_INVALID;

@@ -368,3 +368,28 @@ def test_tiled_ensemble_eval_equals_oracle(n_feat, leaves, rounds):
     m.predict_device(dX.data_ptr(), n, rows.shape[1], dO.data_ptr())
     torch.cuda.synchronize()
     assert np.array_equal(dO.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_device_exp_equals_fdlibm_restatement_everywhere():
+    """both device exps (branch-free fast path, literal e_exp) == the oracle's StrictMath.exp restatement, bit for bit, on the
+    range boundaries of e_exp, around 0, +-0.5 ln2, +-1.5 ln2, the overflow / underflow / subnormal edges, and random arguments"""
+    import ctypes as C
+    edges = [0.0, -0.0, 1.0, -1.0, 2.0 ** -28, 2.0 ** -29, -(2.0 ** -28), 0.5 * np.log(2), 1.5 * np.log(2), 0.34657359027997264,
+             1.0397207708399179, 699.9, 700.0, 700.1, -699.9, -700.1, 709.782712893384, 709.7827128933841, -745.1332191019411,
+             -745.2, -708.3, -708.5, 710.0, np.inf, -np.inf, np.nan, 1e-300, -1e-300, 88.0, -88.0]
+    xs = []
+    for e in edges:
+        if np.isfinite(e) and e != 0:
+            xs += [np.nextafter(e, -np.inf), e, np.nextafter(e, np.inf), -e]
+        else:
+            xs.append(e)
+    rng = np.random.RandomState(5)
+    xs = np.concatenate([np.array(xs), rng.uniform(-40, 40, 20000), rng.uniform(-760, 760, 5000), rng.uniform(-2, 2, 20000),
+                         rng.uniform(-1e-7, 1e-7, 2000)])
+    fast, ref = N.debug_exp(xs)
+    L = O.lib()
+    want = np.array([L.ro_exp(C.c_double(v)) for v in xs])
+    for got in (fast, ref):
+        same = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), xs[~same][:5]
