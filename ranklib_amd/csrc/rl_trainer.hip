@@ -792,6 +792,7 @@ int rl_init(rl_trainer *t)
 
     // ---- per-round state -------------------------------------------------------------------------
     RL_HIP(t->pool.alloc(&c.lambda, (size_t)N)); RL_HIP(t->pool.alloc(&c.weight, (size_t)N));
+    RL_HIP(hipMemset(c.lambda, 0, (size_t)N * sizeof(double))); RL_HIP(hipMemset(c.weight, 0, (size_t)N * sizeof(double)));   // MART never writes weights (MART.java:47-51)
     RL_HIP(t->pool.alloc(&c.q, (size_t)N)); RL_HIP(t->pool.alloc(&c.r, (size_t)N));
     RL_HIP(t->pool.alloc(&c.idx[0], (size_t)N)); RL_HIP(t->pool.alloc(&c.idx[1], (size_t)N));
     RL_HIP(t->pool.alloc(&c.ql[0], (size_t)N)); RL_HIP(t->pool.alloc(&c.ql[1], (size_t)N));

@@ -25,6 +25,10 @@ CASES = {
     "small_ns": (600, 6, "ns", 101, dict(n_trees=6, n_leaves=8, mls=1, k=10, n_threshold=256, lr=0.1)),
     "small_mslr_k3": (900, 5, "mslr", 102, dict(n_trees=5, n_leaves=6, mls=4, k=3, n_threshold=16, lr=0.05)),
     "valid_estop": (700, 4, "ns", 103, dict(n_trees=40, n_leaves=6, mls=1, k=10, n_threshold=256, lr=0.3, early_stop=2)),
+    # MART, and LambdaMART driven by MAP (what the reference's own test uses) and by ERR (the CLI default)
+    "mart_ndcg": (800, 5, "ns", 104, dict(n_trees=6, n_leaves=7, mls=1, k=10, n_threshold=256, lr=0.1, ranker="MART")),
+    "lmart_map": (900, 6, "mslr", 105, dict(n_trees=6, n_leaves=7, mls=1, k=0, n_threshold=256, lr=0.1, metric="MAP")),
+    "lmart_err": (700, 5, "ns", 106, dict(n_trees=5, n_leaves=6, mls=2, k=10, n_threshold=64, lr=0.1, metric="ERR")),
 }
 
 
@@ -70,5 +74,5 @@ def run(name):
 
 
 if __name__ == "__main__":
-    for n in CASES:
+    for n in (sys.argv[1:] or CASES):
         run(n)

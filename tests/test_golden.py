@@ -12,7 +12,7 @@ import oracle_ffi as O
 from tree_equiv import assert_equivalent
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["small_ns", "small_mslr_k3", "valid_estop"]
+CASES = ["small_ns", "small_mslr_k3", "valid_estop", "mart_ndcg", "lmart_map", "lmart_err"]
 
 
 class T:        # adapter for tree_equiv
@@ -62,7 +62,8 @@ def test_hip_path_reproduces_fixture(name):
     from ranklib_amd import _native as N
     z, p = load(name)
     g = N.Trainer(n_trees=p["n_trees"], n_leaves=p["n_leaves"], learning_rate=p["lr"], n_threshold=p["n_threshold"],
-                  min_leaf_support=p["mls"], metric_k=p["k"], early_stop_rounds=p.get("early_stop", 100))
+                  min_leaf_support=p["mls"], metric_k=p["k"], early_stop_rounds=p.get("early_stop", 100),
+                  metric=p.get("metric", "NDCG"), ranker=p.get("ranker", "LAMBDAMART"))
     X = z["X"]
     g.set_train(X, z["labels"], z["qoff"])
     if "Xv" in z:
