@@ -73,8 +73,11 @@ public class LambdaMART extends Ranker {
     @Override
     public void init() {
         logger.info(() -> "Initializing... ");
-        if (!scorer.name().startsWith("NDCG@")) throw RankLibError.create("rlhip: only NDCG@k is built (got " + scorer.name() + ")");
-        handle = RlHipNative.create(nTrees, nTreeLeaves, nThreshold, minLeafSupport, nRoundToStopEarly, learningRate, scorer.getK(), device);
+        final String mname = scorer.name().split("@")[0];                  // "NDCG@10" -> "NDCG", "MAP" -> "MAP"
+        final int metric = "NDCG".equals(mname) ? 0 : "DCG".equals(mname) ? 1 : "MAP".equals(mname) ? 2 : "ERR".equals(mname) ? 3 : -1;
+        if (metric < 0) throw RankLibError.create("rlhip: the train metric must be NDCG, DCG, MAP or ERR (got " + scorer.name() + ")");
+        handle = RlHipNative.create(nTrees, nTreeLeaves, nThreshold, minLeafSupport, nRoundToStopEarly, learningRate, metric, scorer.getK(),
+                rankerId(), device);
         impacts = new double[features.length];
         final Map<String, Integer> qids = new HashMap<>();
         upload(samples, false, qids);
@@ -125,6 +128,9 @@ public class LambdaMART extends Ranker {
     @Override public Ranker createNew() { return new LambdaMART(); }
     @Override public String toString() { return ensemble.toString(); }
     @Override public String name() { return "LambdaMART"; }
+
+    /** RL_RANKER_*: the MART drop-in (same package) overrides this with 0 */
+    protected int rankerId() { return 6; }
     public Ensemble getEnsemble() { return ensemble; }
 
     @Override
