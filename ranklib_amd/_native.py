@@ -168,7 +168,7 @@ class Trainer:
         self.p.metric, self.p.ranker = RL_METRIC[metric.upper()], RL_RANKER[ranker.upper()]
         self.h = C.c_void_p()
         check(L.rl_create(C.byref(self.p), C.byref(self.h)))
-        self.cap = max(1, 2 * n_leaves - 1)
+        self.cap = max(3, 2 * n_leaves - 1)          # the root always splits once (RegressionTree.java:62-67)
         self.N = self.F = self.Q = 0
         self.Nv = 0
         self.has_valid = False

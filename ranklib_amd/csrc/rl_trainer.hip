@@ -375,7 +375,7 @@ static int enqueue_round(rl_trainer *t)
     } else hipLaunchKernelGGL((k_hist_finish<true, false>), dim3(c.F), dim3(kThreads), fin_lds, s, c, nodes_in_lds);
     // Growth steps: each prepares up to kSpec queue nodes and commits as many splits as the fit loop allows; L-1 steps
     // always suffice (every step commits at least the head of the queue); finished trees make the rest no-ops.
-    const int steps = c.L - 1;
+    const int steps = std::max(c.L - 1, 1);
     const size_t slot_words = (size_t)c.F * c.TS * 3 + 4;
     for (int it = 0; it < steps; it++) {
         if (t->dist) {      // local child sizes are unknown in advance: count pass, then scatter
@@ -651,7 +651,9 @@ int rl_init(rl_trainer *t)
     hipStream_t s = t->stream;
     const int N = (int)t->tr.N, F = t->F;
     const int Npad = (N + 127) / 128 * 128;
-    c.N = N; c.Npad = Npad; c.Q = t->tr.Q; c.F = F; c.L = t->p.n_leaves; c.MAXN = 2 * t->p.n_leaves - 1;
+    c.N = N; c.Npad = Npad; c.Q = t->tr.Q; c.F = F; c.L = t->p.n_leaves;
+    // the root is split unconditionally before the leaf budget is looked at (RegressionTree.java:62-67): even -leaf 1 gives 3 nodes
+    c.MAXN = std::max(2 * t->p.n_leaves - 1, 3);
     c.NC = 4 * t->p.n_leaves + 2;     // node records: committed (2L-1) + prepared but never reached (see k_select)
     c.mls = t->p.min_leaf_support; c.lr = t->p.learning_rate;
     c.metric = t->p.metric; c.mart = (t->p.ranker == RL_RANKER_MART) ? 1 : 0;

@@ -139,7 +139,7 @@ class Oracle:
         self.h = self.L.ro_create(C.byref(self.p), self.X.ctypes.data, self.N, self.F, self.labels.ctypes.data,
                                   self.qoff.ctypes.data, self.Q, None if fid is None else fid.ctypes.data,
                                   None if qk is None else qk.ctypes.data)
-        self.cap = max_nodes or (2 * n_leaves - 1 if n_leaves > 0 else 2 * self.N + 1)
+        self.cap = max_nodes or (max(3, 2 * n_leaves - 1) if n_leaves > 0 else 2 * self.N + 1)
         self.has_valid = False
 
     def set_validation(self, X, labels, qoff, qkey=None):

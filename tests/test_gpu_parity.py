@@ -393,3 +393,83 @@ def test_device_exp_equals_fdlibm_restatement_everywhere():
     for got in (fast, ref):
         same = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
         assert same.all(), xs[~same][:5]
+
+
+# ---- edge cases: ragged / degenerate inputs, every way a tree can stop growing -----------------------------------------
+def _edge_cases():
+    rng = np.random.RandomState(11)
+    cases = {}
+    # one-document queries between ordinary ones, a 2-document query, 70 documents in total (less than one wavefront per kernel tile)
+    sizes = [1, 5, 1, 1, 9, 2, 30, 1, 20]
+    n = sum(sizes)
+    cases["ragged_tiny"] = (rng.rand(n, 3).astype(np.float32), rng.randint(0, 5, n).astype(np.float32),
+                            np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32), dict(n_leaves=6, n_trees=4))
+    # every label equal: no active pair, all lambdas 0, the root has deviance 0 -> single-leaf trees of output 0
+    cases["all_labels_equal"] = (rng.rand(300, 4).astype(np.float32), np.full(300, 2, np.float32),
+                                 np.arange(0, 301, 10).astype(np.int32), dict(n_leaves=8, n_trees=3))
+    # all labels 0: ideal DCG 0 -> NDCG 0 for every query
+    cases["all_zero_labels"] = (rng.rand(200, 3).astype(np.float32), np.zeros(200, np.float32), np.arange(0, 201, 20).astype(np.int32),
+                                dict(n_leaves=5, n_trees=2))
+    # constant features: thresholds = {value, MAX_VALUE}, no admissible split anywhere
+    cases["constant_features"] = (np.full((150, 3), 0.25, np.float32), rng.randint(0, 3, 150).astype(np.float32),
+                                  np.arange(0, 151, 15).astype(np.int32), dict(n_leaves=7, n_trees=2))
+    # one feature, two leaves; and min leaf support larger than half the data (root cannot split)
+    X1 = rng.rand(400, 1).astype(np.float32)
+    l1 = (X1[:, 0] * 3).astype(np.int32).astype(np.float32)
+    cases["one_feature_two_leaves"] = (X1, l1, np.arange(0, 401, 8).astype(np.int32), dict(n_leaves=2, n_trees=5))
+    cases["one_leaf"] = (X1, l1, np.arange(0, 401, 8).astype(np.int32), dict(n_leaves=1, n_trees=3))
+    cases["mls_blocks_root"] = (X1, l1, np.arange(0, 401, 8).astype(np.int32), dict(n_leaves=10, n_trees=2, mls=250))
+    cases["mls_stops_children"] = (rng.rand(500, 5).astype(np.float32), rng.randint(0, 5, 500).astype(np.float32),
+                                   np.arange(0, 501, 10).astype(np.int32), dict(n_leaves=31, n_trees=4, mls=60))
+    # more leaves asked for than the data can give (every leaf ends with one distinct row), large labels, duplicate rows
+    Xd = np.repeat(rng.rand(40, 2).astype(np.float32), 3, axis=0)
+    cases["more_leaves_than_rows"] = (Xd, rng.randint(0, 31, 120).astype(np.float32), np.arange(0, 121, 12).astype(np.int32),
+                                      dict(n_leaves=100, n_trees=3))
+    # a single query holding everything
+    cases["single_query"] = (rng.rand(700, 6).astype(np.float32), rng.randint(0, 5, 700).astype(np.float32), np.array([0, 700], np.int32),
+                             dict(n_leaves=12, n_trees=3))
+    return cases
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(_edge_cases()))
+def test_edge_cases_match_the_oracle(name):
+    X, lab, qoff, kw = _edge_cases()[name]
+    o, g = pair(X, lab, qoff, **kw)
+    o.init(); g.init()
+    for r in range(kw["n_trees"]):
+        to, tmo, _, _ = o.round()
+        tg, tmg, _, _ = g.boost_round()
+        assert_same_tree(to, tg, X, "%s round %d" % (name, r))
+        assert np.array_equal(g.array("LAMBDA").view(np.int64), o.lambdas().view(np.int64))
+        assert np.array_equal(g.array("SCORE").view(np.int64), o.scores().view(np.int64))
+        assert np.float32(tmo).view(np.uint32) == np.float32(tmg).view(np.uint32)
+    so, _ = o.finish()
+    sg, _ = g.finish()
+    assert so == sg
+    m = N.Model(g.model_text())
+    rows = np.zeros((X.shape[0], X.shape[1] + 1), np.float32); rows[:, 1:] = X
+    assert np.array_equal(m.predict_rows(rows).view(np.uint32), g.predict(X).view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_bad_inputs_are_rejected_with_ranklib_style_errors():
+    X, lab, qoff = make(200, 3, "ns", 9)
+    for bad, msg in ((np.inf, "finite"), (np.nan, "NaN")):
+        Xb = X.copy(); Xb[17, 1] = bad
+        g = N.Trainer(n_trees=1, n_leaves=4)
+        with pytest.raises(N.RankLibError):
+            g.set_train(Xb, lab, qoff); g.init()
+    g = N.Trainer(n_trees=1, n_leaves=4)
+    with pytest.raises(N.RankLibError):
+        g.set_train(X, -lab - 1, qoff)                      # negative labels (learning/DataPoint.java:71-73)
+    with pytest.raises(N.RankLibError):
+        g.set_train(X, lab, np.array([0, 100, 50, 200], np.int32))      # query offsets must ascend
+    with pytest.raises(N.RankLibError):
+        g.set_train(X[:0], lab[:0], np.array([0], np.int32))            # no data
+    g.set_train(X, lab, qoff)
+    with pytest.raises(N.RankLibError):
+        g.boost_round()                                     # rl_init has not been called
+    g.init(); g.boost_round()
+    with pytest.raises(N.RankLibError):
+        g.boost_round()                                     # more rounds than n_trees
