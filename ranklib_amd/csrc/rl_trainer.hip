@@ -391,6 +391,15 @@ static int enqueue_round(rl_trainer *t)
             int rcd = t->dist->allreduce(c.dist_buf, slot_words * kSpec, DT_I64, OP_SUM, s);
             if (rcd) return rcd;
             hipLaunchKernelGGL((k_hist_finish<false, true>), dim3(c.F, kSpec), dim3(kThreads), fin_lds, s, c, nodes_in_lds);
+            // Sharded runs pay a collective per step even when the tree is already finished, so the host looks at the
+            // (rank-invariant) `done` flag now and then and stops enqueuing: a stream sync costs far less than the
+            // all-reduces of ~20 empty steps.  One GPU keeps the fully asynchronous schedule (an empty step is 3 tiny launches).
+            if (it + 1 < steps && it >= 7 && (it - 7) % 3 == 0) {
+                int32_t done = 0;
+                RL_HIP(hipStreamSynchronize(s));
+                RL_HIP(hipMemcpy(&done, &c.st->done, sizeof(done), hipMemcpyDeviceToHost));
+                if (done) break;
+            }
         } else hipLaunchKernelGGL((k_hist_finish<false, false>), dim3(c.F, kSpec), dim3(kThreads), fin_lds, s, c, nodes_in_lds);
     }
     hipLaunchKernelGGL(k_leaf_table, dim3(1), dim3(64), 0, s, c, t->leaf_chain, t->d_seg_buf);
