@@ -294,7 +294,7 @@ static int launch_rank(rl_trainer *t, DataSet &d, const double *scores, double *
         hipLaunchKernelGGL(k_rank_wave, dim3((d.n_small + 3) / 4), dim3(kThreads), 4 * kLambdaWaveCap * 12, t->stream, a,
                            d.all_small ? (const int *)nullptr : d.d_qsmall, d.n_small);
     if (d.n_big > 0)
-        hipLaunchKernelGGL(k_rank_block, dim3(d.n_big), dim3(kThreads), kLambdaBlockCap * 12, t->stream, a, d.d_qbig, d.n_big);
+        hipLaunchKernelGGL(k_rank_block, dim3(d.n_big), dim3(kRankBlockThreads), kLambdaBlockCap * 12, t->stream, a, d.d_qbig, d.n_big);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
