@@ -69,6 +69,9 @@ struct rl_trainer {
     DataSet tr, va;
     bool has_train = false, has_valid = false, inited = false, finished = false;
     hipStream_t stream = nullptr;
+    // the per-round training metric (a float chain over the queries) is off the critical path of the next round: it runs
+    // on a side stream between two events (single-GPU runs without a validation set)
+    hipStream_t side = nullptr; hipEvent_t ev_ranked = nullptr, ev_metric = nullptr; bool side_pending = false;
     DevPool pool;
     Ctx ctx;
     EnsTree ens;
@@ -249,9 +252,9 @@ static int alloc_chain(rl_trainer *t, ChainBufs &b, int maxseg, int A, int64_t n
 }
 
 // the plan must already be on the device (k_leaf_table / k_plan_single); grids are sized by capacity
-static void enqueue_chain(rl_trainer *t, const ChainBufs &b, const ChainSource &src)
+static void enqueue_chain(rl_trainer *t, const ChainBufs &b, const ChainSource &src, hipStream_t s = nullptr)
 {
-    hipStream_t s = t->stream;
+    if (!s) s = t->stream;
     const unsigned tb = (unsigned)((b.cap_tiles + 3) / 4);
     hipLaunchKernelGGL(k_chain_prefix, dim3(tb, b.A), dim3(kThreads), 0, s, b, src);
     hipLaunchKernelGGL(k_chain_scan_tiles, dim3(b.A), dim3(kThreads), 0, s, b);
@@ -272,13 +275,13 @@ static void enqueue_chain(rl_trainer *t, const ChainBufs &b, const ChainSource &
 }
 
 // float s = 0; for (q) s += ndcg_q; s / Q   -- serial for short lists, exact parallel chain otherwise
-static void enqueue_metric_mean(rl_trainer *t, const double *ndcg_q, int Q, float *out)
+static void enqueue_metric_mean(rl_trainer *t, const double *ndcg_q, int Q, float *out, hipStream_t s = nullptr)
 {
-    hipStream_t s = t->stream;
+    if (!s) s = t->stream;
     if (Q <= 4096 || (t->p.flags & RL_FLAG_SERIAL_CHAIN)) { hipLaunchKernelGGL(k_float_mean, dim3(1), dim3(64), 0, s, ndcg_q, Q, out); return; }
     hipLaunchKernelGGL(k_plan_single, dim3(1), dim3(64), 0, s, t->metric_chain, Q);
     ChainSource src{ndcg_q, nullptr, nullptr, nullptr, nullptr};
-    enqueue_chain(t, t->metric_chain, src);
+    enqueue_chain(t, t->metric_chain, src, s);
     hipLaunchKernelGGL(k_metric_finish, dim3(1), dim3(64), 0, s, t->metric_chain, Q, out);
 }
 
@@ -429,9 +432,17 @@ static int enqueue_round(rl_trainer *t)
     hipLaunchKernelGGL(k_export_tree, dim3(1), dim3(kThreads), 0, s, c, t->ens, m);
     RL_HIP(hipGetLastError());
     // per-round training metric (LambdaMART.java:216)
+    const bool use_side = !t->dist && !t->has_valid;
+    if (use_side && t->side_pending) RL_HIP(hipStreamWaitEvent(s, t->ev_metric, 0));     // the previous round's metric still reads d_ndcg
     int rc = launch_rank(t, t->tr, c.scores, t->tr.d_ndcg, true);      // also the ranking of round m+1's lambdas
     if (rc != RL_OK) return rc;
-    if (t->dist) {
+    if (use_side) {
+        RL_HIP(hipEventRecord(t->ev_ranked, s));
+        RL_HIP(hipStreamWaitEvent(t->side, t->ev_ranked, 0));
+        enqueue_metric_mean(t, t->tr.d_ndcg, t->tr.Q, c.round_metric + 2 * (size_t)m, t->side);
+        RL_HIP(hipEventRecord(t->ev_metric, t->side));
+        t->side_pending = true;
+    } else if (t->dist) {
         const double *gq = nullptr;
         rc = gather_queries(t, t->tr.d_ndcg, &gq);
         if (rc != RL_OK) return rc;
@@ -453,6 +464,7 @@ static int enqueue_round(rl_trainer *t)
 static int sync_rounds(rl_trainer *t)
 {
     RL_HIP(hipStreamSynchronize(t->stream));
+    RL_HIP(hipStreamSynchronize(t->side));
     collect_timing(t);
     TreeState st;
     RL_HIP(hipMemcpy(&st, t->ctx.st, sizeof(st), hipMemcpyDeviceToHost));
@@ -579,6 +591,8 @@ int rl_create(const rl_params *p, rl_trainer **out)
     memset(&t->ctx, 0, sizeof(t->ctx));
     memset(&t->ens, 0, sizeof(t->ens));
     RL_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    RL_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
+    RL_HIP(hipEventCreateWithFlags(&t->ev_ranked, hipEventDisableTiming)); RL_HIP(hipEventCreateWithFlags(&t->ev_metric, hipEventDisableTiming));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
@@ -606,6 +620,9 @@ void rl_destroy(rl_trainer *t)
     if (!t) return;
     (void)hipSetDevice(t->p.device);
     if (t->stream) { (void)hipStreamSynchronize(t->stream); }
+    if (t->side) { (void)hipStreamSynchronize(t->side); (void)hipStreamDestroy(t->side); }
+    if (t->ev_ranked) (void)hipEventDestroy(t->ev_ranked);
+    if (t->ev_metric) (void)hipEventDestroy(t->ev_metric);
     for (int w = 0; w < RL_KERNEL_COUNT_; w++)
         for (auto &pr : t->ev_pending[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : t->ev_free) (void)hipEventDestroy(e);
