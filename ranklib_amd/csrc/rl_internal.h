@@ -19,7 +19,8 @@ constexpr int kMinChunk = 512;       // smallest chunk a (small) node is cut int
 constexpr int kHistDocs = 2;         // samples per thread and iteration of the histogram kernel
 constexpr int kHistFG = 16;          // features per group of the histogram layout gbins[group][doc][kHistFG]
 constexpr int kPartTile = 2048;      // docs per partition tile (256 threads x 8)
-constexpr int kMaxBins = 4096;       // bin stride limit (thresholds per feature incl. MAX_VALUE)
+constexpr int kMaxBins = 4096;       // bin stride limit (thresholds per feature incl. MAX_VALUE); 8 * bin must fit uint16
+constexpr int kHistLdsStride = 264;  // compile-time LDS row stride of the histogram kernels when TS <= 264 (the -tc 256 case: 257)
 constexpr int kHistLdsBytes = 64 * 1024;
 constexpr int kSpec = 4;             // nodes split (speculatively, in queue order) per growth step
 constexpr int kLambdaWaveCap = 384;  // docs/query handled by the wave-per-query lambda kernel

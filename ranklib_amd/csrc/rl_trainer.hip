@@ -306,12 +306,13 @@ template <bool ROOT>
 static void launch_hist(const Ctx &c, int gx, int gy, size_t lds, hipStream_t s)
 {
     const dim3 g(gx, gy), b(kThreads);
+    if (c.sub == 16 && c.TS <= kHistLdsStride) { hipLaunchKernelGGL((k_hist<ROOT, 16, kHistLdsStride>), g, b, lds, s, c); return; }
     switch (c.sub) {
-    case 16: hipLaunchKernelGGL((k_hist<ROOT, 16>), g, b, lds, s, c); break;
-    case 8: hipLaunchKernelGGL((k_hist<ROOT, 8>), g, b, lds, s, c); break;
-    case 4: hipLaunchKernelGGL((k_hist<ROOT, 4>), g, b, lds, s, c); break;
-    case 2: hipLaunchKernelGGL((k_hist<ROOT, 2>), g, b, lds, s, c); break;
-    default: hipLaunchKernelGGL((k_hist<ROOT, 1>), g, b, lds, s, c); break;
+    case 16: hipLaunchKernelGGL((k_hist<ROOT, 16, 0>), g, b, lds, s, c); break;
+    case 8: hipLaunchKernelGGL((k_hist<ROOT, 8, 0>), g, b, lds, s, c); break;
+    case 4: hipLaunchKernelGGL((k_hist<ROOT, 4, 0>), g, b, lds, s, c); break;
+    case 2: hipLaunchKernelGGL((k_hist<ROOT, 2, 0>), g, b, lds, s, c); break;
+    default: hipLaunchKernelGGL((k_hist<ROOT, 1, 0>), g, b, lds, s, c); break;
     }
 }
 
@@ -358,7 +359,7 @@ static int enqueue_round(rl_trainer *t)
     }
     if (t->dist) { int rcd = t->dist->allreduce(&c.st->maxabs_bits, 1, DT_U64, OP_MAX, s); if (rcd) return rcd; }
     hipLaunchKernelGGL(k_quantize, dim3(std::min(2048, (c.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, c);
-    const size_t hist_lds = (size_t)c.sub * c.TS * 8 + (size_t)c.sub * ((c.TS + 1) / 2) * 4;
+    const size_t hist_lds = (size_t)c.sub * ((c.sub == 16 && c.TS <= kHistLdsStride) ? kHistLdsStride : c.TS) * 12;    // int64 sums + int32 counts
     const int hist_gx = c.numFG * (kHistFG / c.sub);
     const size_t red_lds = (size_t)c.TS * 20;
     const int rootCs = std::min(kChunk, std::max(kMinChunk, (((c.N + 63) / 64 + 255) & ~255)));   // == chunk_docs<true>(N)
@@ -593,16 +594,18 @@ int rl_create(const rl_params *p, rl_trainer **out)
     RL_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
     RL_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
     RL_HIP(hipEventCreateWithFlags(&t->ev_ranked, hipEventDisableTiming)); RL_HIP(hipEventCreateWithFlags(&t->ev_metric, hipEventDisableTiming));
-    RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
-    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
-    RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
-    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
-    RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
-    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
-    RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
-    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
-    RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
-    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 16, kHistLdsStride>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 16, kHistLdsStride>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
@@ -748,12 +751,12 @@ int rl_init(rl_trainer *t)
     RL_HIP(hipMemsetAsync(d_thr, 0, (size_t)F * TS * sizeof(float), s));
     RL_HIP(hipMemcpy2DAsync(d_thr, TS * sizeof(float), thr0, TS0 * sizeof(float), TS * sizeof(float), F, hipMemcpyDeviceToDevice, s));
     c.thr = d_thr; c.nthr = d_nthr;
-    if ((size_t)TS * 10 > (size_t)kHistLdsBytes) return fail(RL_ERR_UNSUPPORTED, "too many threshold candidates for the LDS histogram");
+    if ((size_t)TS * 12 > (size_t)kHistLdsBytes) return fail(RL_ERR_UNSUPPORTED, "too many threshold candidates for the LDS histogram");
     // features of a 16-feature group handled by one histogram block: all 16 when the LDS budget allows
     c.FG = kHistFG;
     c.numFG = (F + kHistFG - 1) / kHistFG;
     c.sub = 16;
-    while (c.sub > 1 && (size_t)c.sub * TS * 8 + (size_t)c.sub * ((TS + 1) / 2) * 4 > (size_t)kHistLdsBytes) c.sub >>= 1;
+    while (c.sub > 1 && (size_t)c.sub * TS * 12 > (size_t)kHistLdsBytes) c.sub >>= 1;
 
     uint16_t *d_bins = nullptr, *d_gbins = nullptr;
     RL_HIP(t->pool.alloc(&d_bins, (size_t)F * Npad));
