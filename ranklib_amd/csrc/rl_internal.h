@@ -82,6 +82,7 @@ struct Ctx {
     int32_t N, Npad, Q, F, TS, L, MAXN, NC, mls, k, maxChunks, nTiles, FG, numFG;   // MAXN = 2L-1 tree nodes, NC = node records incl. speculation
     float lr;
     int32_t rank, n_ranks;
+    int32_t node_div, node_min;   // child-node histograms: target chunks per node, smallest chunk (see chunk_docs)
     int32_t mart, metric;    // MART leaf rule (learning/tree/MART.java); RL_METRIC_* of the train metric
     long long *dist_buf;     // [kSpec][F*TS*3 + 4] int64 limbs of the histograms being all-reduced (multi-GPU only)
     // static per data set

@@ -685,6 +685,9 @@ int rl_init(rl_trainer *t)
     c.MAXN = std::max(2 * t->p.n_leaves - 1, 3);
     c.NC = 4 * t->p.n_leaves + 2;     // node records: committed (2L-1) + prepared but never reached (see k_select)
     c.mls = t->p.min_leaf_support; c.lr = t->p.learning_rate;
+    c.node_div = 12; c.node_min = kMinChunk;
+    if (const char *e = getenv("RLHIP_NODE_DIV")) c.node_div = std::max(1, atoi(e));          // tuning knobs (tools/), not API
+    if (const char *e = getenv("RLHIP_NODE_MIN")) c.node_min = std::max(256, atoi(e) & ~255);
     c.metric = t->p.metric; c.mart = (t->p.ranker == RL_RANKER_MART) ? 1 : 0;
     // rows of a ranked list whose pairs the lambda loop visits (LambdaMART.java:375-377: j <= cutoff or k <= cutoff); for
     // NDCG / DCG / ERR row `cutoff` itself only holds zero swap changes
