@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librlhip.so")
+LIB_PATH = os.environ.get("RLHIP_LIB") or os.path.join(_HERE, "lib", "librlhip.so")     # RLHIP_LIB: A/B builds (tools/)
 
 
 class RankLibError(RuntimeError):

@@ -22,7 +22,10 @@ constexpr int kPartTile = 2048;      // docs per partition tile (256 threads x 8
 constexpr int kMaxBins = 4096;       // bin stride limit (thresholds per feature incl. MAX_VALUE); 8 * bin must fit uint16
 constexpr int kHistLdsStride = 264;  // compile-time LDS row stride of the histogram kernels when TS <= 264 (the -tc 256 case: 257)
 constexpr int kHistLdsBytes = 64 * 1024;
-constexpr int kSpec = 4;             // nodes split (speculatively, in queue order) per growth step
+#ifndef RL_KSPEC
+#define RL_KSPEC 4
+#endif
+constexpr int kSpec = RL_KSPEC;      // nodes split (speculatively, in queue order) per growth step
 constexpr int kLambdaWaveCap = 384;  // docs/query handled by the wave-per-query lambda kernel
 constexpr int kLambdaBlockCap = 5000;
 constexpr int kLambdaFusedMaxK = 16;  // NDCG@k up to this k uses the LDS-resident fused lambda kernel
