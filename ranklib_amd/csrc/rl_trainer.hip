@@ -86,6 +86,7 @@ struct rl_trainer {
     ChainBufs leaf_chain, metric_chain;      // exact parallel float chains (rl_chain.inc)
     int32_t *d_seg_buf = nullptr;
     double2 *d_T = nullptr;                  // pair terms of the lambda computation [N][k]
+    double *d_wmax = nullptr;                // per-block max |lambda| of the lambda launches
     float *d_vmetric = nullptr;
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending[RL_KERNEL_COUNT_];
@@ -335,28 +336,33 @@ static int enqueue_round(rl_trainer *t)
     const int m = t->round;
     // round scalars
     RL_HIP(hipMemsetAsync(&c.st->maxabs_bits, 0, sizeof(unsigned long long) + sizeof(long long), s));
+    int n_max = 0;       // blocks that reported their max |lambda| (folded by k_max_reduce)
     if (c.mart) {    // MART: residuals instead of lambdas (weights stay 0)
         ScopedTiming tm(t, RL_KERNEL_LAMBDA, (double)c.N * 20.0);
-        hipLaunchKernelGGL(k_mart_residual, dim3(std::min(2048, (c.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
-                           c.labels, (const double *)c.scores, c.lambda, c.N, &c.st->maxabs_bits);
+        n_max = std::min(2048, (c.N + kThreads - 1) / kThreads);
+        hipLaunchKernelGGL(k_mart_residual, dim3(n_max), dim3(kThreads), 0, s, c.labels, (const double *)c.scores, c.lambda, c.N, t->d_wmax);
     } else {   // K1 lambdas: pair terms in parallel, then ordered accumulation (ranked order comes from the previous
         // round's k_rank_* / from rl_init for round 0)
         ScopedTiming tm(t, RL_KERNEL_LAMBDA, (double)c.N * 28.0);
         const double *ideal = (c.metric == RL_METRIC_NDCG) ? (m == 0 ? c.ideal0 : c.ideal1) : nullptr;
         LamArgs g{t->tr.d_ss, t->tr.d_sl, t->tr.d_srel, t->tr.d_sidx, c.qoff, t->tr.d_docq, ideal, c.disc,
                   t->d_T, c.lambda, c.weight, &c.st->maxabs_bits, c.N, c.k, c.k, c.metric, t->p.metric_k,
-                  t->tr.d_aux_i, t->tr.d_aux_a, t->tr.d_aux_b};
+                  t->tr.d_aux_i, t->tr.d_aux_a, t->tr.d_aux_b, t->d_wmax};
         if (t->d_T == nullptr) {
             const size_t l128 = (size_t)c.k * 128 * 16 + (size_t)c.k * 24 + 128 * 4;
             const size_t l256 = (size_t)c.k * 256 * 16 + (size_t)c.k * 24 + 256 * 4;
             if (t->tr.n_q128 > 0) hipLaunchKernelGGL(k_lambda_fused<128>, dim3(t->tr.n_q128), dim3(128), l128, s, g, (const int *)t->tr.d_q128, t->tr.n_q128);
+            g.blockmax = t->d_wmax + t->tr.n_q128;
             if (t->tr.n_qlong > 0) hipLaunchKernelGGL(k_lambda_fused<256>, dim3(t->tr.n_qlong), dim3(256), l256, s, g, (const int *)t->tr.d_qlong, t->tr.n_qlong);
+            n_max = t->tr.n_q128 + t->tr.n_qlong;
         } else {
             const unsigned nb = (unsigned)((c.N + kThreads - 1) / kThreads);
             hipLaunchKernelGGL(k_pair_terms, dim3(nb), dim3(kThreads), 0, s, g);
             hipLaunchKernelGGL(k_lambda_acc, dim3(nb), dim3(kThreads), 0, s, g);
+            n_max = (int)nb;
         }
     }
+    hipLaunchKernelGGL(k_max_reduce, dim3(1), dim3(1024), 0, s, (const double *)t->d_wmax, n_max, &c.st->maxabs_bits);
     if (t->dist) { int rcd = t->dist->allreduce(&c.st->maxabs_bits, 1, DT_U64, OP_MAX, s); if (rcd) return rcd; }
     hipLaunchKernelGGL(k_quantize, dim3(std::min(2048, (c.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, c);
     const size_t hist_lds = (size_t)c.sub * ((c.sub == 16 && c.TS <= kHistLdsStride) ? kHistLdsStride : c.TS) * 12;    // int64 sums + int32 counts
@@ -906,6 +912,7 @@ int rl_init(rl_trainer *t)
             if ((size_t)N * c.k * sizeof(double2) > ((size_t)16 << 30)) return fail(RL_ERR_UNSUPPORTED, "this metric cutoff needs more than 16 GiB of pair terms");
             RL_HIP(t->pool.alloc(&t->d_T, (size_t)N * c.k));
         }
+        RL_HIP(t->pool.alloc(&t->d_wmax, (size_t)std::max(std::max(d.Q, (N + kThreads - 1) / kThreads), 2048) + 1));
         if (c.metric == RL_METRIC_MAP) RL_HIP(t->pool.alloc(&d.d_aux_i, (size_t)N));
         if (c.metric == RL_METRIC_ERR) { RL_HIP(t->pool.alloc(&d.d_aux_a, (size_t)N)); RL_HIP(t->pool.alloc(&d.d_aux_b, (size_t)N)); }
         RL_HIP(hipDeviceSynchronize());
