@@ -349,8 +349,8 @@ static int enqueue_round(rl_trainer *t)
                   t->d_T, c.lambda, c.weight, &c.st->maxabs_bits, c.N, c.k, c.k, c.metric, t->p.metric_k,
                   t->tr.d_aux_i, t->tr.d_aux_a, t->tr.d_aux_b, t->d_wmax};
         if (t->d_T == nullptr) {
-            const size_t l128 = (size_t)c.k * 128 * 16 + (size_t)c.k * 24 + 128 * 4;
-            const size_t l256 = (size_t)c.k * 256 * 16 + (size_t)c.k * 24 + 256 * 4;
+            const size_t l128 = (size_t)c.k * 128 * 16 + (size_t)c.k * 24;
+            const size_t l256 = (size_t)c.k * 256 * 16 + (size_t)c.k * 24;
             if (t->tr.n_q128 > 0) hipLaunchKernelGGL(k_lambda_fused<128>, dim3(t->tr.n_q128), dim3(128), l128, s, g, (const int *)t->tr.d_q128, t->tr.n_q128);
             g.blockmax = t->d_wmax + t->tr.n_q128;
             if (t->tr.n_qlong > 0) hipLaunchKernelGGL(k_lambda_fused<256>, dim3(t->tr.n_qlong), dim3(256), l256, s, g, (const int *)t->tr.d_qlong, t->tr.n_qlong);
@@ -689,7 +689,7 @@ int rl_init(rl_trainer *t)
     c.N = N; c.Npad = Npad; c.Q = t->tr.Q; c.F = F; c.L = t->p.n_leaves;
     // the root is split unconditionally before the leaf budget is looked at (RegressionTree.java:62-67): even -leaf 1 gives 3 nodes
     c.MAXN = std::max(2 * t->p.n_leaves - 1, 3);
-    c.NC = 4 * t->p.n_leaves + 2;     // node records: committed (2L-1) + prepared but never reached (see k_select)
+    c.NC = 4 * t->p.n_leaves + 2;     // node records: committed (2L-1) + prepared but never reached (see select_step)
     c.mls = t->p.min_leaf_support; c.lr = t->p.learning_rate;
     c.node_div = 12; c.node_min = kMinChunk;
     if (const char *e = getenv("RLHIP_NODE_DIV")) c.node_div = std::max(1, atoi(e));          // tuning knobs (tools/), not API
