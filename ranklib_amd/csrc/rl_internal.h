@@ -12,6 +12,7 @@ namespace rl {
 
 constexpr int kThreads = 256;        // 4 wavefronts of 64
 constexpr int kWave = 64;
+constexpr int kFinThreads = 320;     // k_hist_finish / k_hist_reduce blocks: 5 wavefronts cover the 257 bins of -tc 256 in one pass
 constexpr int kLog2Chunk = 14;       // max docs accumulated into one int64 LDS accumulator (fixes the fixed-point exponent)
 constexpr int kChunk = 1 << kLog2Chunk;   // chunk of the root histogram
 constexpr int kNodeChunk = 8192;     // largest chunk of a child-node histogram

@@ -378,11 +378,11 @@ static int enqueue_round(rl_trainer *t)
     const int nodes_in_lds = (select_lds_bytes(c.L, c.NC, true) <= 60 * 1024) ? 1 : 0;
     const size_t fin_lds = std::max((size_t)c.TS * 20, select_lds_bytes(c.L, c.NC, nodes_in_lds != 0));
     if (t->dist) {
-        hipLaunchKernelGGL(k_hist_reduce, dim3(c.F), dim3(kThreads), red_lds, s, c, 1);
+        hipLaunchKernelGGL(k_hist_reduce, dim3(c.F), dim3(kFinThreads), red_lds, s, c, 1);
         int rcd = t->dist->allreduce(c.dist_buf, (size_t)c.F * c.TS * 3 + 4, DT_I64, OP_SUM, s);
         if (rcd) return rcd;
-        hipLaunchKernelGGL((k_hist_finish<true, true>), dim3(c.F), dim3(kThreads), fin_lds, s, c, nodes_in_lds);
-    } else hipLaunchKernelGGL((k_hist_finish<true, false>), dim3(c.F), dim3(kThreads), fin_lds, s, c, nodes_in_lds);
+        hipLaunchKernelGGL((k_hist_finish<true, true>), dim3(c.F), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
+    } else hipLaunchKernelGGL((k_hist_finish<true, false>), dim3(c.F), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
     // Growth steps: each prepares up to kSpec queue nodes and commits as many splits as the fit loop allows; L-1 steps
     // always suffice (every step commits at least the head of the queue); finished trees make the rest no-ops.
     const int steps = std::max(c.L - 1, 1);
@@ -397,10 +397,10 @@ static int enqueue_round(rl_trainer *t)
             launch_hist<false>(c, hist_gx, c.maxChunks, hist_lds, s);
         }
         if (t->dist) {
-            hipLaunchKernelGGL(k_hist_reduce, dim3(c.F, kSpec), dim3(kThreads), red_lds, s, c, 0);
+            hipLaunchKernelGGL(k_hist_reduce, dim3(c.F, kSpec), dim3(kFinThreads), red_lds, s, c, 0);
             int rcd = t->dist->allreduce(c.dist_buf, slot_words * kSpec, DT_I64, OP_SUM, s);
             if (rcd) return rcd;
-            hipLaunchKernelGGL((k_hist_finish<false, true>), dim3(c.F, kSpec), dim3(kThreads), fin_lds, s, c, nodes_in_lds);
+            hipLaunchKernelGGL((k_hist_finish<false, true>), dim3(c.F, kSpec), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
             // Sharded runs pay a collective per step even when the tree is already finished, so the host looks at the
             // (rank-invariant) `done` flag now and then and stops enqueuing: a stream sync costs far less than the
             // all-reduces of ~20 empty steps.  One GPU keeps the fully asynchronous schedule (an empty step is 3 tiny launches).
@@ -410,7 +410,7 @@ static int enqueue_round(rl_trainer *t)
                 RL_HIP(hipMemcpy(&done, &c.st->done, sizeof(done), hipMemcpyDeviceToHost));
                 if (done) break;
             }
-        } else hipLaunchKernelGGL((k_hist_finish<false, false>), dim3(c.F, kSpec), dim3(kThreads), fin_lds, s, c, nodes_in_lds);
+        } else hipLaunchKernelGGL((k_hist_finish<false, false>), dim3(c.F, kSpec), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
     }
     hipLaunchKernelGGL(k_leaf_table, dim3(1), dim3(64), 0, s, c, t->leaf_chain, t->d_seg_buf);
     if (t->p.flags & RL_FLAG_SERIAL_CHAIN) {
