@@ -17,9 +17,15 @@ constexpr int kLog2Chunk = 14;       // max docs accumulated into one int64 LDS 
 constexpr int kChunk = 1 << kLog2Chunk;   // chunk of the root histogram
 constexpr int kNodeChunk = 8192;     // largest chunk of a child-node histogram
 constexpr int kMinChunk = 512;       // smallest chunk a (small) node is cut into
-constexpr int kHistDocs = 2;         // samples per thread and iteration of the histogram kernel
+#ifndef RL_HIST_DOCS
+#define RL_HIST_DOCS 2
+#endif
+constexpr int kHistDocs = RL_HIST_DOCS;         // samples per thread and iteration of the histogram kernel
 constexpr int kHistFG = 16;          // features per group of the histogram layout gbins[group][doc][kHistFG]
-constexpr int kPartTile = 2048;      // docs per partition tile (256 threads x 8)
+#ifndef RL_PART_TILE
+#define RL_PART_TILE 2048
+#endif
+constexpr int kPartTile = RL_PART_TILE;      // docs per partition tile (256 threads x 8)
 constexpr int kMaxBins = 4096;       // bin stride limit (thresholds per feature incl. MAX_VALUE); 8 * bin must fit uint16
 constexpr int kHistLdsStride = 264;  // compile-time LDS row stride of the histogram kernels when TS <= 264 (the -tc 256 case: 257)
 constexpr int kHistLdsBytes = 64 * 1024;
