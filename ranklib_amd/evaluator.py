@@ -42,6 +42,69 @@ class Evaluator:
             logger.info("Model saved to: %s", modelFile)
         return ranker
 
+    def _features(self, featureDefFile, samples):
+        return FeatureManager.readFeature(featureDefFile) if featureDefFile else FeatureManager.getFeatureFromSampleVector(samples)
+
+    def _train(self, train, validation, features):
+        trainer = RankerTrainer()
+        if validation is not None:
+            return trainer.train(self.type, train, validation, features, self.trainScorer)
+        return trainer.train(self.type, train, features, self.trainScorer)
+
+    def evaluate_tts(self, sampleFile, validationFile, featureDefFile, percentTrain, modelFile=None):     # -tts  :716-739
+        samples = FeatureManager.readInput(sampleFile)
+        features = self._features(featureDefFile, samples)
+        train, test = FeatureManager.prepareSplit(samples, percentTrain)
+        validation = FeatureManager.readInput(validationFile) if validationFile else None
+        ranker = self._train(train, validation, features)
+        s = self.testScorer.score(ranker.rank(test))
+        logger.info("%s on test data: %s", self.testScorer.name(), java_round(s, 4))
+        if modelFile:
+            ranker.save(modelFile)
+            logger.info("Model saved to: %s", modelFile)
+        return ranker, s
+
+    def evaluate_tvs(self, trainFile, percentTrain, testFile, featureDefFile, modelFile=None):            # -tvs  :749-773
+        samples = FeatureManager.readInput(trainFile)
+        features = self._features(featureDefFile, samples)
+        train, validation = FeatureManager.prepareSplit(samples, percentTrain)
+        test = FeatureManager.readInput(testFile) if testFile else None
+        ranker = self._train(train, validation, features)
+        s = None
+        if test is not None:
+            s = self.testScorer.score(ranker.rank(test))
+            logger.info("%s on test data: %s", self.testScorer.name(), java_round(s, 4))
+        if modelFile:
+            ranker.save(modelFile)
+            logger.info("Model saved to: %s", modelFile)
+        return ranker, s
+
+    def evaluate_kcv(self, sampleFile, featureDefFile, nFold, tvs=-1.0, modelDir="", modelFile=""):      # -kcv  :798-873
+        samples = FeatureManager.readInput(sampleFile)
+        features = self._features(featureDefFile, samples)
+        trainingData, validationData, testData = FeatureManager.prepareCV(samples, nFold, tvs)
+        scores, scoreOnTrain, scoreOnTest, totalScoreOnTest, totalTestSampleSize = [], 0.0, 0.0, 0.0, 0
+        for i in range(nFold):
+            ranker = self._train(trainingData[i], validationData[i] if tvs > 0 else None, features)
+            s2 = self.testScorer.score(ranker.rank(testData[i]))
+            scoreOnTrain += ranker.getScoreOnTrainingData()
+            scoreOnTest += s2
+            totalScoreOnTest += s2 * len(testData[i])
+            totalTestSampleSize += len(testData[i])
+            scores.append((ranker.getScoreOnTrainingData(), s2))
+            if modelDir:
+                import os
+                os.makedirs(modelDir, exist_ok=True)
+                ranker.save(os.path.join(modelDir, "f%d.%s" % (i + 1, modelFile)))
+                logger.info("Fold-%d model saved to: %s", i + 1, modelFile)
+        logger.info("Summary:")
+        logger.info("%s\t|   Train\t| Test", self.testScorer.name())
+        for i, (a, b) in enumerate(scores):
+            logger.info("Fold %d\t|   %s\t|  %s\t", i + 1, java_round(a, 4), java_round(b, 4))
+        logger.info("Avg.\t|   %s\t|  %s\t", java_round(scoreOnTrain / nFold, 4), java_round(scoreOnTest / nFold, 4))
+        logger.info("Total\t|   \t\t|  %s\t", java_round(totalScoreOnTest / totalTestSampleSize, 4))
+        return scores
+
     def score(self, modelFile, testFile, outputFile):      # :1076-1094: qid \t index \t score
         ranker = self.rFact.loadRankerFromFile(modelFile)
         test = FeatureManager.readInput(testFile)
@@ -78,6 +141,8 @@ def main(argv=None):
     trainFile = validationFile = testFile = featureDescriptionFile = savedModelFile = rankFile = indriRankingFile = scoreFile = modelFile = ""
     rankerType = 4                                          # the reference's default is Coordinate Ascent (:83)
     trainMetric, testMetric = "ERR@10", ""                  # the reference's default train metric (:84)
+    ttSplit = tvSplit = 0.0
+    foldCV, kcvModelDir, kcvModelFile = -1, "", ""
     i = 0
     while i < len(args):                                    # :230-372 (flags are matched case-insensitively)
         a = args[i].lower()
@@ -109,7 +174,12 @@ def main(argv=None):
         elif a == "-mls": LambdaMART.minLeafSupport = int(nxt())
         elif a == "-estop": LambdaMART.nRoundToStopEarly = int(nxt())
         elif a == "-thread": nxt()                          # CPU thread pool of the reference: irrelevant here
-        elif a in ("-frate", "-srate", "-bag", "-round", "-epoch", "-tolerance", "-reg", "-r", "-i", "-norm", "-kcv", "-tvs", "-tts",
+        elif a == "-tts": ttSplit = float(nxt())            # :245-250
+        elif a == "-tvs": tvSplit = float(nxt())
+        elif a == "-kcv": foldCV = int(nxt())
+        elif a == "-kcvmd": kcvModelDir = nxt()
+        elif a == "-kcvmn": kcvModelFile = nxt()
+        elif a in ("-frate", "-srate", "-bag", "-round", "-epoch", "-tolerance", "-reg", "-r", "-i", "-norm",
                    "-layer", "-node", "-lr", "-noeq", "-max", "-rtype", "-l2"):
             # parameters of the other rankers / of flows that are out of scope: parsed (the reference's own test passes
             # -frate -bag -round -epoch to every ranker, test:eval/EvaluatorTest.java:207-220) and ignored
@@ -125,7 +195,18 @@ def main(argv=None):
         raise RankLibError("rlhip builds -ranker 6 (LambdaMART) and -ranker 0 (MART) only")
     e = Evaluator(RankerType(rankerType) if rankerType in (0, 6) else RankerType.LAMBDAMART, trainMetric, testMetric)
     if trainFile:
-        e.evaluate(trainFile, validationFile or None, testFile or None, featureDescriptionFile or None, modelFile or None)
+        if foldCV != -1:                                    # :469-482
+            if kcvModelDir and not kcvModelFile:
+                kcvModelFile = "kcv"
+            elif not kcvModelDir and kcvModelFile:
+                kcvModelDir = "kcvmodels"
+            e.evaluate_kcv(trainFile, featureDescriptionFile or None, foldCV, tvSplit if tvSplit > 0 else -1.0, kcvModelDir, kcvModelFile)
+        elif ttSplit > 0.0:                                 # -tts overrides -tvs (:484-486)
+            e.evaluate_tts(trainFile, validationFile or None, featureDescriptionFile or None, ttSplit, modelFile or None)
+        elif tvSplit > 0.0:
+            e.evaluate_tvs(trainFile, tvSplit, testFile or None, featureDescriptionFile or None, modelFile or None)
+        else:
+            e.evaluate(trainFile, validationFile or None, testFile or None, featureDescriptionFile or None, modelFile or None)
     elif savedModelFile:
         if rankFile and indriRankingFile:
             e.rank(savedModelFile, rankFile, indriRankingFile)

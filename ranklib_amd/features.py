@@ -61,3 +61,36 @@ class FeatureManager:
             raise RankLibError("Error in FeatureManager::getFeatureFromSampleVector(): There are no training samples.")
         fc = max(rl.getFeatureCount() for rl in samples)
         return list(range(1, fc + 1))
+
+    @staticmethod
+    def prepareSplit(samples, percentTrain):           # features/FeatureManager.java:432-443 (no shuffling: file order)
+        size = int(len(samples) * percentTrain)
+        return [RankList(rl) for rl in samples[:size]], [RankList(rl) for rl in samples[size:]]
+
+    @staticmethod
+    def prepareCV(samples, nFold, tvs=-1.0):           # :349-413: contiguous folds, the last one takes the remainder
+        size = len(samples) // nFold
+        folds, start, total = [], 0, 0
+        for _ in range(nFold):
+            t = [start + i for i in range(size) if start + i < len(samples)]
+            folds.append(t)
+            total += len(t)
+            start += size
+        while total < len(samples):
+            folds[-1].append(total)
+            total += 1
+        trainingData, validationData, testData = [], [], []
+        for t in folds:
+            ts = set(t)
+            train = [RankList(samples[j]) for j in range(len(samples)) if j not in ts]
+            test = [RankList(samples[j]) for j in range(len(samples)) if j in ts]
+            vali = []
+            if tvs > 0:                                # the LAST lists of the training part, taken back to front (:391-397)
+                validationSize = int(len(train) * (1.0 - tvs))
+                for _ in range(validationSize):
+                    vali.append(train.pop())
+            trainingData.append(train)
+            testData.append(test)
+            if tvs > 0:
+                validationData.append(vali)
+        return trainingData, validationData, testData

@@ -138,3 +138,42 @@ def test_reference_test_flow_verbatim(tmp_path, rnum, header):
         else:
             n_rank = min(rank, n_rank)
         assert p_rank < n_rank and p_rank == 1
+
+
+def _lists(n):
+    return [learning.RankList([learning.DataPoint("%d qid:q%d 1:%d" % (i % 3, i, i))]) for i in range(n)]
+
+
+def test_split_helpers_follow_feature_manager():
+    s = _lists(11)
+    tr, te = features.FeatureManager.prepareSplit(s, 0.7)               # (int)(11 * 0.7) = 7, file order kept
+    assert [r.getID() for r in tr] == ["q%d" % i for i in range(7)] and [r.getID() for r in te] == ["q7", "q8", "q9", "q10"]
+    trains, valis, tests = features.FeatureManager.prepareCV(s, 3, 0.75)   # folds of 3, the last takes the remainder (5)
+    assert [[r.getID() for r in t] for t in tests] == [["q0", "q1", "q2"], ["q3", "q4", "q5"], ["q6", "q7", "q8", "q9", "q10"]]
+    # fold 0: 8 training lists, (int)(8 * 0.25) = 2 go to validation, taken from the END, back to front
+    assert [r.getID() for r in valis[0]] == ["q10", "q9"] and [r.getID() for r in trains[0]] == ["q3", "q4", "q5", "q6", "q7", "q8"]
+    trains, valis, tests = features.FeatureManager.prepareCV(s, 2)
+    assert valis == [] and [len(t) for t in tests] == [5, 6] and [len(t) for t in trains] == [6, 5]
+
+
+@pytest.mark.gpu
+def test_cli_tvs_tts_kcv_flows(tmp_path):
+    data = str(tmp_path / "d.txt")
+    rng = np.random.RandomState(3)
+    with open(data, "w") as f:
+        for q in range(24):
+            for d in range(8):
+                x = rng.rand(3)
+                f.write("%d qid:%d 1:%f 2:%f 3:%f # d%d_%d\n" % (int(x[0] * 3), q, x[0], x[1], x[2], q, d))
+    saved = (learning.LambdaMART.nTrees, learning.LambdaMART.nTreeLeaves)
+    try:
+        evaluator.main(["-train", data, "-ranker", "6", "-metric2t", "NDCG@5", "-tree", "8", "-leaf", "4", "-tvs", "0.75",
+                        "-save", str(tmp_path / "m1.txt")])
+        evaluator.main(["-train", data, "-ranker", "6", "-metric2t", "NDCG@5", "-tree", "8", "-leaf", "4", "-tts", "0.5"])
+        evaluator.main(["-train", data, "-ranker", "0", "-metric2t", "NDCG@5", "-tree", "5", "-leaf", "4", "-kcv", "3", "-tvs", "0.8",
+                        "-kcvmd", str(tmp_path / "cv"), "-kcvmn", "m"])
+    finally:
+        learning.LambdaMART.nTrees, learning.LambdaMART.nTreeLeaves = saved
+    assert open(tmp_path / "m1.txt").read().startswith("## LambdaMART\n## No. of trees = 8\n")
+    assert sorted(p.name for p in (tmp_path / "cv").iterdir()) == ["f1.m", "f2.m", "f3.m"]
+    assert open(tmp_path / "cv" / "f2.m").read().startswith("## MART\n")
