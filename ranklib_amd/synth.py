@@ -43,7 +43,7 @@ def uniform01(seed, stream, index):
 
 def query_sizes(n_docs, kind="mslr", seed=SEED_QSIZE):
     """query offsets (int32, Q+1) whose sizes sum to exactly n_docs"""
-    mean = 120.0 if kind == "mslr" else 10.0
+    mean = {"mslr": 120.0, "yahoo": 24.0}.get(kind, 10.0)
     est = int(n_docs / mean * 1.6) + 64
     while True:
         i = np.arange(est, dtype=np.uint64)
@@ -54,8 +54,10 @@ def query_sizes(n_docs, kind="mslr", seed=SEED_QSIZE):
             n = np.clip(np.rint(120.0 * np.exp(0.5 * z) / np.exp(0.125)), 1, 1251).astype(np.int64)
         elif kind == "ns":
             n = 5 + (uniform01(seed, 1, i).astype(np.float64) * 11).astype(np.int64)
+        elif kind == "yahoo":             # Yahoo-set1 shape: ~24 documents per query
+            n = 5 + (uniform01(seed, 1, i).astype(np.float64) * 39).astype(np.int64)
         else:
-            raise ValueError("kind must be 'mslr' or 'ns'")
+            raise ValueError("kind must be 'mslr', 'ns' or 'yahoo'")
         c = np.cumsum(n)
         if c[-1] >= n_docs:
             break
@@ -67,13 +69,22 @@ def query_sizes(n_docs, kind="mslr", seed=SEED_QSIZE):
     return off.astype(np.int32)
 
 
-def features(n_docs, n_features, doc_start=0, seed=SEED_DATA, out=None):
-    """row-major float32 [n_docs, n_features] for docs doc_start..doc_start+n_docs-1"""
+def features(n_docs, n_features, doc_start=0, seed=SEED_DATA, out=None, sparse=False):
+    """row-major float32 [n_docs, n_features] for docs doc_start..doc_start+n_docs-1.
+    sparse (Yahoo-set1 shape): 181 of every 700 columns are all zero, the others are 85 % zeros."""
     X = out if out is not None else np.empty((n_docs, n_features), dtype=np.float32)
     docs = np.arange(doc_start, doc_start + n_docs, dtype=np.uint64)
     for f in range(n_features):
         u = uniform01(seed, 1000 + f, docs)
         fam = f % 4
+        if sparse:
+            if (f * 2654435761 % 700) < 181 and f >= 20:          # the first 20 columns stay informative (labels use some)
+                X[:, f] = 0
+                continue
+            gate = uniform01(seed, 9000 + f, docs)
+            dense = u if fam != 2 else np.exp(4.0 * u.astype(np.float64)).astype(np.float32)
+            X[:, f] = np.where((gate < np.float32(0.85)) & (f >= 20), np.float32(0), dense)
+            continue
         if fam == 0:
             col = np.floor(u.astype(np.float64) ** 2 * 21.0).astype(np.float32)
         elif fam == 1:
@@ -112,7 +123,7 @@ def labels_from(X, doc_start=0, seed=SEED_LABEL, cuts=None):
 def make_dataset(n_docs, n_features=136, kind="mslr", seed_offset=0):
     """(X float32 [N,F] row-major, labels float32 [N], qoff int32 [Q+1])"""
     qoff = query_sizes(n_docs, kind, SEED_QSIZE + seed_offset)
-    X = features(n_docs, n_features, 0, SEED_DATA + seed_offset)
+    X = features(n_docs, n_features, 0, SEED_DATA + seed_offset, sparse=(kind == "yahoo"))
     lab, _ = labels_from(X, 0, SEED_LABEL + seed_offset)
     return X, lab, qoff
 
@@ -123,6 +134,7 @@ SHAPES = {
     "c1": (1_200_000, 136, "mslr", 1000, 31),
     "c1ns": (1_200_000, 136, "ns", 1000, 31),
     "c2": (3_770_000, 136, "mslr", 1000, 31),
+    "c3": (473_000, 700, "yahoo", 1000, 31),      # Yahoo-set1 shape: sparse, 700 features (181 empty)
 }
 
 
@@ -134,15 +146,16 @@ def make_shard(n_docs, n_features=136, kind="mslr", rank=0, world=1, seed_offset
     qb, qe = D.partition_queries(qoff, world)[rank]
     d0, d1 = int(qoff[qb]), int(qoff[qe])
     ns = min(cut_sample, n_docs)
-    Xs = features(ns, n_features, 0, SEED_DATA + seed_offset)
+    sp = (kind == "yahoo")
+    Xs = features(ns, n_features, 0, SEED_DATA + seed_offset, sparse=sp)
     _, cuts = labels_from(Xs, 0, SEED_LABEL + seed_offset)
     if d0 == 0 and d1 <= ns:
         X = Xs[:d1]
     elif d0 == 0:
         X = np.empty((d1, n_features), dtype=np.float32)
         X[:ns] = Xs
-        features(d1 - ns, n_features, ns, SEED_DATA + seed_offset, out=X[ns:])
+        features(d1 - ns, n_features, ns, SEED_DATA + seed_offset, out=X[ns:], sparse=sp)
     else:
-        X = features(d1 - d0, n_features, d0, SEED_DATA + seed_offset)
+        X = features(d1 - d0, n_features, d0, SEED_DATA + seed_offset, sparse=sp)
     lab, _ = labels_from(X, d0, SEED_LABEL + seed_offset, cuts=cuts)
     return X, lab, (qoff[qb:qe + 1] - qoff[qb]).astype(np.int32), int(len(qoff) - 1)

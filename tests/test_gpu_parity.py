@@ -473,3 +473,20 @@ def test_bad_inputs_are_rejected_with_ranklib_style_errors():
     g.init(); g.boost_round()
     with pytest.raises(N.RankLibError):
         g.boost_round()                                     # more rounds than n_trees
+
+
+@pytest.mark.gpu
+def test_sparse_700_feature_shape_matches_the_oracle():
+    """Yahoo-set1 shape in small: 700 columns, 175 of them all zero (one threshold + MAX_VALUE, never
+    split on), the rest 85 % zeros; the tree learner densifies everything, so only the column count changes"""
+    X, lab, qoff = make(6000, 700, "yahoo", 31)
+    o, g = pair(X, lab, qoff, n_trees=3, n_leaves=12)
+    o.init(); g.init()
+    nb = g.array("NBINS")
+    assert (nb[np.abs(X).sum(0) == 0] == 2).all()
+    for r in range(3):
+        to, tmo, _, _ = o.round()
+        tg, tmg, _, _ = g.boost_round()
+        assert_same_tree(to, tg, X, "round %d" % r)
+        assert np.array_equal(g.array("SCORE").view(np.int64), o.scores().view(np.int64))
+        assert np.float32(tmo).view(np.uint32) == np.float32(tmg).view(np.uint32)
