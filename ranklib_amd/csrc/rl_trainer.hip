@@ -349,8 +349,8 @@ static int enqueue_round(rl_trainer *t)
                   t->d_T, c.lambda, c.weight, &c.st->maxabs_bits, c.N, c.k, c.k, c.metric, t->p.metric_k,
                   t->tr.d_aux_i, t->tr.d_aux_a, t->tr.d_aux_b, t->d_wmax};
         if (t->d_T == nullptr) {
-            const size_t l128 = (size_t)c.k * 128 * 16 + (size_t)c.k * 24;
-            const size_t l256 = (size_t)c.k * 256 * 16 + (size_t)c.k * 24;
+            const size_t l128 = (size_t)c.k * (128 + 8) * 16 + (size_t)c.k * 24;
+            const size_t l256 = (size_t)c.k * (256 + 8) * 16 + (size_t)c.k * 24;
             if (t->tr.n_q128 > 0) hipLaunchKernelGGL(k_lambda_fused<128>, dim3(t->tr.n_q128), dim3(128), l128, s, g, (const int *)t->tr.d_q128, t->tr.n_q128);
             g.blockmax = t->d_wmax + t->tr.n_q128;
             if (t->tr.n_qlong > 0) hipLaunchKernelGGL(k_lambda_fused<256>, dim3(t->tr.n_qlong), dim3(256), l256, s, g, (const int *)t->tr.d_qlong, t->tr.n_qlong);
