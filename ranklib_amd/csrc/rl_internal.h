@@ -80,6 +80,7 @@ struct TreeState {
     unsigned long long maxabs_bits;   // max |lambda| of the round (bit pattern, monotone for x >= 0)
     long long root_sq;                // sum over all docs of rint(lambda^2 * 2^E2)
     SlotRec slot[kSpec];
+    int32_t arrive1[kSpec][16];        // first-level arrival counters of k_hist_finish (<= 16 feature groups per slot)
 };
 
 // one kept tree of the ensemble, nodes in creation order
