@@ -76,7 +76,8 @@ struct TreeState {
     int32_t n_nodes, nslots, done, taken;
     int32_t qsize, n_leaves, E, E2;
     int32_t n_splits, error, tiles_total, chunks_total;
-    int32_t arrive, epoch, pad0, pad1;    // finish blocks arrived (last one runs select_step); growth step counter (look-back tags)
+    int32_t arrive, epoch, step, tree_seq;    // finish blocks arrived (last one runs select_step); growth step counter (look-back tags);
+                                              // select_step calls in this tree; trees started (both mirrored by the host, see Ctx::progress)
     unsigned long long maxabs_bits;   // max |lambda| of the round (bit pattern, monotone for x >= 0)
     long long root_sq;                // sum over all docs of rint(lambda^2 * 2^E2)
     SlotRec slot[kSpec];
@@ -128,6 +129,9 @@ struct Ctx {
     int32_t *leaf_node, *leaf_start;                                   // [MAXN], [MAXN+1]
     int32_t *grow_stats;                                               // [4] cumulative: growth steps, nodes prepared, splits committed, trees
     float *round_metric;                                               // [n_trees][2]
+    // host-visible (pinned, fine-grained) growth progress: tree_seq << 32 | select_step calls in the tree << 1 | done.
+    // A HINT only: the host uses it to stop enqueuing growth steps of a finished tree (extra steps are no-ops).
+    unsigned long long *progress;
 };
 
 void set_error(const std::string &msg);

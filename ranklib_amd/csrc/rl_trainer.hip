@@ -7,6 +7,7 @@
 // There is no CPU fallback anywhere in this file: without a gfx950 device rl_create fails with
 // RL_ERR_NO_DEVICE.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -76,6 +77,9 @@ struct rl_trainer {
     Ctx ctx;
     EnsTree ens;
     int32_t round = 0;          // rounds enqueued so far
+    // growth progress reported by the device (Ctx::progress): the host keeps at most `step_ahead` growth steps in flight and
+    // stops enqueuing steps of a finished tree; 0 = enqueue all L-1 steps blindly
+    unsigned long long *h_progress = nullptr; uint32_t tree_seq = 0; int32_t step_ahead = 3;
     int32_t synced_rounds = 0;
     int32_t n_kept = 0;         // trees kept after rollback (== round until rl_finish)
     int32_t best_round = 2147483647 - 2;     // LambdaMART.bestModelOnValidation  LambdaMART.java:50
@@ -257,20 +261,18 @@ static void enqueue_chain(rl_trainer *t, const ChainBufs &b, const ChainSource &
 {
     if (!s) s = t->stream;
     const unsigned tb = (unsigned)((b.cap_tiles + 3) / 4);
-    hipLaunchKernelGGL(k_chain_prefix, dim3(tb, b.A), dim3(kThreads), 0, s, b, src);
+    hipLaunchKernelGGL(k_chain_prefix, dim3(tb), dim3(kThreads), 0, s, b, src);
     hipLaunchKernelGGL(k_chain_scan_tiles, dim3(b.A), dim3(kThreads), 0, s, b);
     hipLaunchKernelGGL(k_chain_bounds, dim3(tb, b.A), dim3(kThreads), 0, s, b);
     hipLaunchKernelGGL(k_chain_pass1, dim3((unsigned)((b.cap_chunks * 16 + kThreads - 1) / kThreads), b.A), dim3(kThreads), 0, s, b);
     hipLaunchKernelGGL(k_chain_guess, dim3(b.A), dim3(kThreads), 0, s, b);
     const dim3 tgrid((unsigned)((b.cap_chunks * kChainW + kThreads - 1) / kThreads), b.A);
-    const dim3 cgrid((unsigned)((b.cap_chunks + kThreads - 1) / kThreads), b.A);
-    hipLaunchKernelGGL(k_chain_tables<false>, tgrid, dim3(kThreads), 0, s, b);
+    hipLaunchKernelGGL(k_chain_tables<false>, tgrid, dim3(kThreads), 0, s, b, 0);
     const size_t lds = (size_t)(b.cap_chunks / kChainGroup + 2) * kChainW * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_chain_stitch, dim3(b.maxseg, b.A), dim3(kThreads), lds, s, b);
+    hipLaunchKernelGGL(k_chain_stitch, dim3(b.maxseg, b.A), dim3(kThreads), lds, s, b, 0);
     for (int rep = 0; rep < kChainRepairs; rep++) {      // near-empty launches unless a window was missed
-        hipLaunchKernelGGL(k_chain_tables<true>, tgrid, dim3(kThreads), 0, s, b);
-        hipLaunchKernelGGL(k_chain_commit, cgrid, dim3(kThreads), 0, s, b);
-        hipLaunchKernelGGL(k_chain_stitch, dim3(b.maxseg, b.A), dim3(kThreads), lds, s, b);
+        hipLaunchKernelGGL(k_chain_tables<true>, tgrid, dim3(kThreads), 0, s, b, rep & 1);
+        hipLaunchKernelGGL(k_chain_stitch, dim3(b.maxseg, b.A), dim3(kThreads), lds, s, b, (rep & 1) ^ 1);
     }
     hipLaunchKernelGGL(k_chain_fallback, dim3(b.maxseg, b.A), dim3(64), 0, s, b);
 }
@@ -387,7 +389,24 @@ static int enqueue_round(rl_trainer *t)
     // always suffice (every step commits at least the head of the queue); finished trees make the rest no-ops.
     const int steps = std::max(c.L - 1, 1);
     const size_t slot_words = (size_t)c.F * c.TS * 3 + 4;
+    t->tree_seq++;
+    bool throttle = c.progress != nullptr;
     for (int it = 0; it < steps; it++) {
+        if (throttle && it >= t->step_ahead) {
+            // wait (bounded) until growth step it - step_ahead has been selected, then look at the tree's done flag.  Purely a
+            // scheduling hint: on a timeout the remaining steps are enqueued blindly, which is always correct.
+            const unsigned long long want = ((unsigned long long)t->tree_seq << 32) | ((unsigned long long)(unsigned)(it - t->step_ahead) << 1);
+            const auto finished = [&](unsigned long long w) { return (w >> 32) == t->tree_seq && (w & 1); };
+            unsigned long long w = __atomic_load_n(t->h_progress, __ATOMIC_ACQUIRE);
+            if (w < want && !finished(w)) {
+                const auto t0 = std::chrono::steady_clock::now();
+                unsigned spins = 0;
+                while ((w = __atomic_load_n(t->h_progress, __ATOMIC_ACQUIRE)) < want && !finished(w)) {
+                    if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) { throttle = false; break; }
+                }
+            }
+            if (finished(w)) break;
+        }
         if (t->dist) {      // local child sizes are unknown in advance: count pass, then scatter
             hipLaunchKernelGGL(k_part_count, dim3(c.nTiles), dim3(kThreads), 0, s, c);
             hipLaunchKernelGGL(k_part_scatter<false>, dim3(c.nTiles), dim3(kThreads), 0, s, c);
@@ -419,7 +438,7 @@ static int enqueue_round(rl_trainer *t)
         // multi-GPU: gather lambda / weight in leaf order from every rank and evaluate the chains over the whole leaf
         ChainSource src{c.lambda, c.weight, c.idx[0], c.idx[1], t->d_seg_buf};
         const ChainBufs &lb = t->leaf_chain;
-        hipLaunchKernelGGL(k_chain_prefix, dim3((unsigned)((lb.cap_tiles + 3) / 4), lb.A), dim3(kThreads), 0, s, lb, src);
+        hipLaunchKernelGGL(k_chain_prefix, dim3((unsigned)((lb.cap_tiles + 3) / 4)), dim3(kThreads), 0, s, lb, src);
         int rcd = t->dist->allgather(lb.xs, t->d_gx, (size_t)lb.A * lb.cap_n * sizeof(double), s);
         if (rcd) return rcd;
         rcd = t->dist->allgather(c.leaf_start, t->d_gls, (size_t)t->lsstride * sizeof(int32_t), s);
@@ -636,6 +655,7 @@ void rl_destroy(rl_trainer *t)
         for (auto &pr : t->ev_pending[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : t->ev_free) (void)hipEventDestroy(e);
     if (t->stream) (void)hipStreamDestroy(t->stream);
+    if (t->h_progress) (void)hipHostFree(t->h_progress);
     delete t;
 }
 
@@ -839,6 +859,12 @@ int rl_init(rl_trainer *t)
     RL_HIP(t->pool.alloc(&c.rl[0], (size_t)N)); RL_HIP(t->pool.alloc(&c.rl[1], (size_t)N));
     RL_HIP(t->pool.alloc(&c.nodes, (size_t)c.NC + 2)); RL_HIP(t->pool.alloc(&c.st, (size_t)1));
     RL_HIP(hipMemset(c.st, 0, sizeof(TreeState)));
+    t->tree_seq = 0;
+    if (const char *e = getenv("RLHIP_STEP_AHEAD")) t->step_ahead = std::max(0, atoi(e));     // tuning knob
+    if (!t->h_progress) RL_HIP(hipHostMalloc((void **)&t->h_progress, sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+    *t->h_progress = 0;
+    c.progress = nullptr;
+    if (t->step_ahead > 0 && !t->dist) RL_HIP(hipHostGetDevicePointer((void **)&c.progress, t->h_progress, 0));
     RL_HIP(hipMemset(c.nodes, 0, ((size_t)c.NC + 2) * sizeof(NodeRec)));
     RL_HIP(t->pool.alloc(&c.queue, (size_t)c.MAXN + 2));
     RL_HIP(t->pool.alloc(&c.part_sum, (size_t)c.maxChunks * F * TS)); RL_HIP(t->pool.alloc(&c.part_cnt, (size_t)c.maxChunks * F * TS));
