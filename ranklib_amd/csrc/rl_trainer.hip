@@ -80,6 +80,7 @@ struct rl_trainer {
     // growth progress reported by the device (Ctx::progress): the host keeps at most `step_ahead` growth steps in flight and
     // stops enqueuing steps of a finished tree; 0 = enqueue all L-1 steps blindly
     unsigned long long *h_progress = nullptr; uint32_t tree_seq = 0; int32_t step_ahead = 3;
+    unsigned long long chain_seq = 0; std::vector<void *> pinned;     // chain pass tags; pinned words of the chains (freed in rl_destroy)
     int32_t synced_rounds = 0;
     int32_t n_kept = 0;         // trees kept after rollback (== round until rl_finish)
     int32_t best_round = 2147483647 - 2;     // LambdaMART.bestModelOnValidation  LambdaMART.java:50
@@ -228,15 +229,25 @@ static void collect_timing(rl_trainer *t)
 
 
 // ---- exact parallel float chains (rl_chain.inc) ------------------------------------------------------
-static int alloc_chain(rl_trainer *t, ChainBufs &b, int maxseg, int A, int64_t n)
+static size_t chain_stitch_lds(const ChainBufs &b)
+{
+    const size_t ng1 = (size_t)(b.cap_chunks / b.group + 2), ng2 = ng1 / kChainSuper + 2;
+    return (ng1 * (kChainW + 1) + ng2 * kChainW) * sizeof(uint32_t);
+}
+
+static int alloc_chain(rl_trainer *t, ChainBufs &b, int maxseg, int A, int64_t n, bool hint = false)
 {
     memset(&b, 0, sizeof(b));
     b.maxseg = maxseg; b.A = A;
     b.cap_tiles = n / kChainTile + maxseg + 2;
     b.cap_chunks = b.cap_tiles + maxseg + 2;
     b.cap_n = std::max<int64_t>(n, b.cap_chunks);
-    if (b.cap_chunks / kChainGroup + 2 > (160 * 1024) / (kChainW * 4))
-        return fail(RL_ERR_UNSUPPORTED, "data set too large for the float-chain stitch kernel");
+    // stitch tables in LDS: first-level groups of `group` chunks (the smaller the group, the shorter the chain of dependent loads)
+    b.group = 8;
+    while (chain_stitch_lds(b) > 152 * 1024) {
+        b.group *= 2;
+        if (b.group > 65536) return fail(RL_ERR_UNSUPPORTED, "data set too large for the float-chain stitch kernel");
+    }
     RL_HIP(t->pool.alloc(&b.plan, (size_t)1));
     RL_HIP(t->pool.alloc(&b.seg_start, (size_t)maxseg + 2)); RL_HIP(t->pool.alloc(&b.seg_tile0, (size_t)maxseg + 2));
     RL_HIP(t->pool.alloc(&b.xs, (size_t)A * b.cap_n)); RL_HIP(t->pool.alloc(&b.pre, (size_t)A * b.cap_n));
@@ -250,6 +261,13 @@ static int alloc_chain(rl_trainer *t, ChainBufs &b, int maxseg, int A, int64_t n
     RL_HIP(t->pool.alloc(&b.st_key, (size_t)A * maxseg)); RL_HIP(t->pool.alloc(&b.st_delta, (size_t)A * maxseg));
     RL_HIP(hipMemset(b.st_status, 0, (size_t)A * maxseg * sizeof(int32_t)));
     RL_HIP(hipMemset(b.miss, 0, (size_t)A * maxseg * sizeof(int32_t)));
+    RL_HIP(t->pool.alloc(&b.arrive, (size_t)1)); RL_HIP(hipMemset(b.arrive, 0, sizeof(unsigned long long)));
+    if (hint) {
+        RL_HIP(hipHostMalloc((void **)&b.h_progress, sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+        *b.h_progress = 0;
+        RL_HIP(hipHostGetDevicePointer((void **)&b.progress, b.h_progress, 0));
+        t->pinned.push_back(b.h_progress);
+    }
     RL_HIP(t->pool.alloc(&b.stats, (size_t)4));
     RL_HIP(hipMemset(b.stats, 0, 4 * sizeof(int32_t)));
     RL_HIP(hipMemset(b.plan, 0, sizeof(ChainPlan)));
@@ -257,24 +275,48 @@ static int alloc_chain(rl_trainer *t, ChainBufs &b, int maxseg, int A, int64_t n
 }
 
 // the plan must already be on the device (k_leaf_table / k_plan_single); grids are sized by capacity
+// bounded wait on a pinned progress word written by the device (a scheduling hint, never a correctness dependency)
+template <class Pred>
+static bool spin_until(const unsigned long long *word, Pred ok, unsigned long long &w)
+{
+    w = __atomic_load_n(word, __ATOMIC_ACQUIRE);
+    if (ok(w)) return true;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 1;; spins++) {
+        w = __atomic_load_n(word, __ATOMIC_ACQUIRE);
+        if (ok(w)) return true;
+        if ((spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) return false;
+    }
+}
+
 static void enqueue_chain(rl_trainer *t, const ChainBufs &b, const ChainSource &src, hipStream_t s = nullptr)
 {
     if (!s) s = t->stream;
     const unsigned tb = (unsigned)((b.cap_tiles + 3) / 4);
     hipLaunchKernelGGL(k_chain_prefix, dim3(tb), dim3(kThreads), 0, s, b, src);
-    hipLaunchKernelGGL(k_chain_scan_tiles, dim3(b.A), dim3(kThreads), 0, s, b);
+    hipLaunchKernelGGL(k_chain_scan_tiles, dim3(b.A), dim3(kScanThreads), 0, s, b);
     hipLaunchKernelGGL(k_chain_bounds, dim3(tb, b.A), dim3(kThreads), 0, s, b);
     hipLaunchKernelGGL(k_chain_pass1, dim3((unsigned)((b.cap_chunks * 16 + kThreads - 1) / kThreads), b.A), dim3(kThreads), 0, s, b);
-    hipLaunchKernelGGL(k_chain_guess, dim3(b.A), dim3(kThreads), 0, s, b);
+    hipLaunchKernelGGL(k_chain_guess, dim3(b.A), dim3(kScanThreads), 0, s, b);
     const dim3 tgrid((unsigned)((b.cap_chunks * kChainW + kThreads - 1) / kThreads), b.A);
+    const size_t lds = chain_stitch_lds(b);
+    // every stitch pass carries a tag; with a progress word (ChainBufs::h_progress) the host looks at the result of the pass
+    // before the last one it enqueued and leaves the remaining repair passes (near-empty launches) away once nothing is open
+    const unsigned long long seq = ++t->chain_seq;
+    bool hint = b.h_progress != nullptr && t->step_ahead > 0, clean = false;
     hipLaunchKernelGGL(k_chain_tables<false>, tgrid, dim3(kThreads), 0, s, b, 0);
-    const size_t lds = (size_t)(b.cap_chunks / kChainGroup + 2) * kChainW * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_chain_stitch, dim3(b.maxseg, b.A), dim3(kThreads), lds, s, b, 0);
-    for (int rep = 0; rep < kChainRepairs; rep++) {      // near-empty launches unless a window was missed
+    hipLaunchKernelGGL(k_chain_stitch, dim3(b.maxseg, b.A), dim3(kScanThreads), lds, s, b, 0, seq << 8);
+    for (int rep = 0; rep < kChainRepairs; rep++) {
+        if (hint && rep >= 1) {
+            const unsigned long long want = (seq << 8) | (unsigned)(rep - 1);      // stitch of repair pass rep-2 (0 = the first stitch)
+            unsigned long long w;
+            if (!spin_until(b.h_progress, [&](unsigned long long v) { return (v >> 1) >= want; }, w)) hint = false;
+            else if ((w >> 9) == seq && !(w & 1)) { clean = true; break; }
+        }
         hipLaunchKernelGGL(k_chain_tables<true>, tgrid, dim3(kThreads), 0, s, b, rep & 1);
-        hipLaunchKernelGGL(k_chain_stitch, dim3(b.maxseg, b.A), dim3(kThreads), lds, s, b, (rep & 1) ^ 1);
+        hipLaunchKernelGGL(k_chain_stitch, dim3(b.maxseg, b.A), dim3(kScanThreads), lds, s, b, (rep & 1) ^ 1, (seq << 8) | (unsigned)(rep + 1));
     }
-    hipLaunchKernelGGL(k_chain_fallback, dim3(b.maxseg, b.A), dim3(64), 0, s, b);
+    if (!clean) hipLaunchKernelGGL(k_chain_fallback, dim3(b.maxseg, b.A), dim3(64), 0, s, b);
 }
 
 // float s = 0; for (q) s += ndcg_q; s / Q   -- serial for short lists, exact parallel chain otherwise
@@ -431,7 +473,7 @@ static int enqueue_round(rl_trainer *t)
             }
         } else hipLaunchKernelGGL((k_hist_finish<false, false>), dim3(c.F, kSpec), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
     }
-    hipLaunchKernelGGL(k_leaf_table, dim3(1), dim3(64), 0, s, c, t->leaf_chain, t->d_seg_buf);
+    hipLaunchKernelGGL(k_leaf_table, dim3(1), dim3(kThreads), 0, s, c, t->leaf_chain, t->d_seg_buf);
     if (t->p.flags & RL_FLAG_SERIAL_CHAIN) {
         hipLaunchKernelGGL(k_leaf_chain, dim3(c.L), dim3(64), 0, s, c);
     } else if (t->dist) {
@@ -656,6 +698,7 @@ void rl_destroy(rl_trainer *t)
     for (auto e : t->ev_free) (void)hipEventDestroy(e);
     if (t->stream) (void)hipStreamDestroy(t->stream);
     if (t->h_progress) (void)hipHostFree(t->h_progress);
+    for (void *q : t->pinned) (void)hipHostFree(q);
     delete t;
 }
 
@@ -906,13 +949,13 @@ int rl_init(rl_trainer *t)
             }
             if (t->Nglobal >= (int64_t)2147483647 - 4096) return fail(RL_ERR_UNSUPPORTED, "more than 2^31 documents in total");
         }
-        int rc = alloc_chain(t, t->leaf_chain, c.MAXN + 1, 2, Nmax);
+        int rc = alloc_chain(t, t->leaf_chain, c.MAXN + 1, 2, Nmax, true);
         if (rc) return rc;
         rc = alloc_chain(t, t->metric_chain, 1, 1, std::max(t->Qglobal, t->has_valid ? t->va.Q : 0));
         if (rc) return rc;
         RL_HIP(t->pool.alloc(&t->d_seg_buf, (size_t)c.MAXN + 2));
         if (t->dist) {
-            rc = alloc_chain(t, t->gchain, c.MAXN + 1, 2, t->Nglobal);
+            rc = alloc_chain(t, t->gchain, c.MAXN + 1, 2, t->Nglobal, true);
             if (rc) return rc;
             t->lsstride = c.MAXN + 2;
             RL_HIP(t->pool.alloc(&t->d_gx, (size_t)t->n_ranks * 2 * t->leaf_chain.cap_n));
