@@ -210,6 +210,10 @@ enum {
 /* The device's two exp implementations (rho of learning/tree/LambdaMART.java:383) on n arguments: the branch-free one the
  * lambda kernels use and the literal fdlibm e_exp transcription; both must equal StrictMath.exp bit for bit. */
 int rl_debug_exp(const double *x, int32_t n, double *out_fast, double *out_ref);
+/* The exact parallel evaluation of Java float running sums (`float s = 0; for (k) s += x[k];`, learning/tree/LambdaMART.java:401-408,
+ * :474-483) on arbitrary data: n doubles cut into n_seg segments (seg_start[0] = 0 ... seg_start[n_seg] = n), out[s] = the float
+ * sum of segment s.  stats (may be null): int32[4] = segments evaluated, window misses repaired, segments finished serially, 0. */
+int rl_debug_float_chain(int32_t device, const double *x, int64_t n, const int64_t *seg_start, int32_t n_seg, float *out, int32_t *stats);
 int rl_bin_stride(const rl_trainer *t, int32_t *stride);
 int rl_quant_exponent(const rl_trainer *t, int32_t *e);   /* q = rint(lambda * 2^e) in the last round */
 int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes);

@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "rl_set_train", "rl_set_validation", "rl_init", "rl_boost_round", "rl_boost_rounds_async", "rl_sync",
     "rl_finish", "rl_num_trees", "rl_get_tree", "rl_get_round_metrics", "rl_best_validation", "rl_predict",
     "rl_model_to_text", "rl_model_from_text", "rl_model_destroy", "rl_model_num_trees", "rl_model_features",
-    "rl_model_predict", "rl_model_predict_device", "rl_dist_unique_id", "rl_dist_init", "rl_dist_init_callback", "rl_bin_stride", "rl_quant_exponent", "rl_get_array", "rl_debug_exp",
+    "rl_model_predict", "rl_model_predict_device", "rl_dist_unique_id", "rl_dist_init", "rl_dist_init_callback", "rl_bin_stride", "rl_quant_exponent", "rl_get_array", "rl_debug_exp", "rl_debug_float_chain",
     "rl_get_timing", "rl_reset_timing",
 ]
 
@@ -102,6 +102,7 @@ def lib():
     L.rl_quant_exponent.argtypes = [vp, C.POINTER(i32)]
     L.rl_get_array.argtypes = [vp, i32, vp, i64]
     L.rl_debug_exp.argtypes = [vp, i32, vp, vp]
+    L.rl_debug_float_chain.argtypes = [i32, vp, i64, vp, i32, vp, vp]
     L.rl_get_timing.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
     L.rl_reset_timing.argtypes = [vp]
     _lib = L
@@ -152,6 +153,16 @@ def debug_exp(x):
     a, b = np.zeros_like(x), np.zeros_like(x)
     check(lib().rl_debug_exp(x.ctypes.data, len(x), a.ctypes.data, b.ctypes.data))
     return a, b
+
+
+def debug_float_chain(x, seg_start=None, device=0):
+    """Java float running sums of the segments of x on the GPU (rl_chain.inc); returns (float32 sums, int32[4] stats)."""
+    x = np.ascontiguousarray(x, np.float64)
+    seg = np.ascontiguousarray([0, len(x)] if seg_start is None else seg_start, np.int64)
+    out = np.zeros(len(seg) - 1, np.float32)
+    stats = np.zeros(4, np.int32)
+    check(lib().rl_debug_float_chain(device, x.ctypes.data, len(x), seg.ctypes.data, len(seg) - 1, out.ctypes.data, stats.ctypes.data))
+    return out, stats
 
 
 class Trainer:

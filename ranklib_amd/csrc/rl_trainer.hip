@@ -298,7 +298,7 @@ static void enqueue_chain(rl_trainer *t, const ChainBufs &b, const ChainSource &
     hipLaunchKernelGGL(k_chain_bounds, dim3(tb, b.A), dim3(kThreads), 0, s, b);
     hipLaunchKernelGGL(k_chain_pass1, dim3((unsigned)((b.cap_chunks * 16 + kThreads - 1) / kThreads), b.A), dim3(kThreads), 0, s, b);
     hipLaunchKernelGGL(k_chain_guess, dim3(b.A), dim3(kScanThreads), 0, s, b);
-    const dim3 tgrid((unsigned)((b.cap_chunks * kChainW + kThreads - 1) / kThreads), b.A);
+    const dim3 tgrid((unsigned)((b.cap_chunks + kThreads / 64 - 1) / (kThreads / 64)), b.A);       // one wavefront per chunk
     const size_t lds = chain_stitch_lds(b);
     // every stitch pass carries a tag; with a progress word (ChainBufs::h_progress) the host looks at the result of the pass
     // before the last one it enqueued and leaves the remaining repair passes (near-empty launches) away once nothing is open
@@ -1304,6 +1304,43 @@ int rl_debug_exp(const double *x, int32_t n, double *out_fast, double *out_ref)
     RL_HIP(hipMemcpy(out_fast, d + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     RL_HIP(hipMemcpy(out_ref, d + 2 * (size_t)n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     (void)hipFree(d);
+    return RL_OK;
+}
+
+int rl_debug_float_chain(int32_t device, const double *x, int64_t n, const int64_t *seg_start, int32_t n_seg, float *out, int32_t *stats)
+{
+    if (!x || !seg_start || !out || n < 0 || n_seg < 1 || n > 2147483647 / 2) return fail(RL_ERR_INVALID, "bad argument");
+    for (int i = 0; i < n_seg; i++) if (seg_start[i] > seg_start[i + 1]) return fail(RL_ERR_INVALID, "segments must be ascending");
+    if (seg_start[0] != 0 || seg_start[n_seg] != n) return fail(RL_ERR_INVALID, "segments must cover [0, n)");
+    RL_HIP(hipSetDevice(device));
+    std::unique_ptr<rl_trainer> t(new rl_trainer());      // only the pool, the stream and the chain bookkeeping are used
+    memset(&t->ctx, 0, sizeof(t->ctx)); memset(&t->ens, 0, sizeof(t->ens)); memset(&t->p, 0, sizeof(t->p));
+    t->p.device = device;
+    RL_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    RL_HIP(hipFuncSetAttribute((const void *)k_chain_stitch, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    struct Guard { rl_trainer *t; ~Guard() { (void)hipStreamSynchronize(t->stream); (void)hipStreamDestroy(t->stream); for (void *q : t->pinned) (void)hipHostFree(q); } } guard{t.get()};
+    ChainBufs b;
+    int rc = alloc_chain(t.get(), b, n_seg, 1, n, true);
+    if (rc) return rc;
+    std::vector<int32_t> ss(n_seg + 1), st0(n_seg + 1);
+    int32_t tiles = 0;
+    for (int i = 0; i <= n_seg; i++) {
+        ss[i] = (int32_t)seg_start[i]; st0[i] = tiles;
+        if (i < n_seg) tiles += (int32_t)((seg_start[i + 1] - seg_start[i] + kChainTile - 1) / kChainTile);
+    }
+    ChainPlan plan{n_seg, tiles, tiles + n_seg, (int32_t)n};
+    double *dx = nullptr;
+    RL_HIP(t->pool.alloc(&dx, (size_t)std::max<int64_t>(n, 1)));
+    RL_HIP(hipMemcpy(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    RL_HIP(hipMemcpy(b.seg_start, ss.data(), ss.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    RL_HIP(hipMemcpy(b.seg_tile0, st0.data(), st0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    RL_HIP(hipMemcpy(b.plan, &plan, sizeof(plan), hipMemcpyHostToDevice));
+    ChainSource src{dx, nullptr, nullptr, nullptr, nullptr};
+    enqueue_chain(t.get(), b, src);
+    RL_HIP(hipGetLastError());
+    RL_HIP(hipStreamSynchronize(t->stream));
+    RL_HIP(hipMemcpy(out, b.result, (size_t)n_seg * sizeof(float), hipMemcpyDeviceToHost));
+    if (stats) RL_HIP(hipMemcpy(stats, b.stats, 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
     return RL_OK;
 }
 

@@ -276,6 +276,39 @@ def test_exact_parallel_float_chain_equals_serial_chain_and_oracle():
     print("chain stats (leaf: evaluated, misses repaired, serial finishes; metric: same):", st_a)
 
 
+def _chain_cases():
+    rng = np.random.default_rng(77)
+    n = 300_000
+    lam = rng.standard_normal(n) * np.exp(rng.standard_normal(n) * 3)
+    yield "lambda-like", lam, None
+    yield "positive weights", np.abs(lam) * 1e-3, None
+    tiny = lam.copy(); tiny[::7] = 1e-45; tiny[::11] = -4.9e-324; tiny[::13] = -0.0
+    yield "denormal and zero elements", tiny, None
+    yield "all tiny: float subnormal sums", np.full(5000, 1.4e-45) * rng.integers(-3, 4, 5000), None
+    yield "all zero / negative zero", np.where(rng.random(4000) < 0.5, 0.0, -0.0), None
+    big = lam.copy(); big[1000] = 3e38; big[50_000] = -3e38; big[200_000] = 1e39
+    yield "overflow to infinity", big, None
+    nanv = lam[:20_000].copy(); nanv[7777] = np.nan
+    yield "NaN", nanv, None
+    yield "cancellation", np.tile(np.array([1.0, -1.0 + 2.0 ** -52, 1e-30, -1e-30, 16777216.0, 1.0, -16777216.0]), 9000), None
+    seg = np.sort(np.concatenate([[0, 0, 1, 2, 513, 1024, n, n], rng.integers(0, n, 40)]))
+    yield "ragged segments (empty, 1 element, tile edges)", lam, seg
+    yield "single element", np.array([0.1]), None
+
+
+@pytest.mark.parametrize("case", list(_chain_cases()), ids=lambda c: c[0].split(" (")[0].replace(" ", "_"))
+def test_float_chain_kernels_on_adversarial_data_equal_the_serial_java_sum(case):
+    """rl_debug_float_chain (rl_chain.inc: window tables, repair passes, serial finish) == the oracle's literal
+    `float s += x` loop (LambdaMART.java:401-408), bit for bit"""
+    name, x, seg = case
+    seg = np.array([0, len(x)]) if seg is None else seg
+    got, stats = N.debug_float_chain(x, seg)
+    want = np.array([O.float_chain(x[seg[i]:seg[i + 1]]) for i in range(len(seg) - 1)], np.float32)
+    both_nan = np.isnan(got) & np.isnan(want)           # NaN payloads are not part of the contract (Java prints NaN)
+    assert np.array_equal(got.view(np.uint32)[~both_nan], want.view(np.uint32)[~both_nan]), (name, got[:8], want[:8], stats)
+    print(name, "stats", stats.tolist())
+
+
 @pytest.mark.parametrize("k", [1, 3, 16, 20, 1000])
 def test_ndcg_cutoffs_fused_and_general_lambda_paths(k):
     """NDCG@k for k <= 16 runs the LDS-fused lambda kernel, larger k the global-matrix kernels; k >= list length too"""
