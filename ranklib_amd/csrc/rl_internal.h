@@ -110,7 +110,8 @@ struct Ctx {
     const double *ideal0, *ideal1;  // [Q] ideal DCG used by swapChange in round 0 / later (NDCGScorer cache quirk)
     const double *disc;     // discount table, >= maxq+2 entries
     // per round
-    double *scores, *lambda, *weight, *ndcg_q;
+    double *scores, *ndcg_q;
+    double2 *lw;             // [N] (lambda, weight) of the round, interleaved: the leaf chains gather both with one 16-byte load
     long long *q, *r;
     int32_t *idx[2];
     long long *ql[2];        // fixed-point lambda in sample-list order (travels with idx through the partitions)

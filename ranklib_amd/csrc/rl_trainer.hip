@@ -325,7 +325,7 @@ static void enqueue_metric_mean(rl_trainer *t, const double *ndcg_q, int Q, floa
     if (!s) s = t->stream;
     if (Q <= 4096 || (t->p.flags & RL_FLAG_SERIAL_CHAIN)) { hipLaunchKernelGGL(k_float_mean, dim3(1), dim3(64), 0, s, ndcg_q, Q, out); return; }
     hipLaunchKernelGGL(k_plan_single, dim3(1), dim3(64), 0, s, t->metric_chain, Q);
-    ChainSource src{ndcg_q, nullptr, nullptr, nullptr, nullptr};
+    ChainSource src{ndcg_q, nullptr, nullptr, nullptr, nullptr, nullptr};
     enqueue_chain(t, t->metric_chain, src, s);
     hipLaunchKernelGGL(k_metric_finish, dim3(1), dim3(64), 0, s, t->metric_chain, Q, out);
 }
@@ -384,13 +384,13 @@ static int enqueue_round(rl_trainer *t)
     if (c.mart) {    // MART: residuals instead of lambdas (weights stay 0)
         ScopedTiming tm(t, RL_KERNEL_LAMBDA, (double)c.N * 20.0);
         n_max = std::min(2048, (c.N + kThreads - 1) / kThreads);
-        hipLaunchKernelGGL(k_mart_residual, dim3(n_max), dim3(kThreads), 0, s, c.labels, (const double *)c.scores, c.lambda, c.N, t->d_wmax);
+        hipLaunchKernelGGL(k_mart_residual, dim3(n_max), dim3(kThreads), 0, s, c.labels, (const double *)c.scores, c.lw, c.N, t->d_wmax);
     } else {   // K1 lambdas: pair terms in parallel, then ordered accumulation (ranked order comes from the previous
         // round's k_rank_* / from rl_init for round 0)
         ScopedTiming tm(t, RL_KERNEL_LAMBDA, (double)c.N * 28.0);
         const double *ideal = (c.metric == RL_METRIC_NDCG) ? (m == 0 ? c.ideal0 : c.ideal1) : nullptr;
         LamArgs g{t->tr.d_ss, t->tr.d_sl, t->tr.d_srel, t->tr.d_sidx, c.qoff, t->tr.d_docq, ideal, c.disc,
-                  t->d_T, c.lambda, c.weight, &c.st->maxabs_bits, c.N, c.k, c.k, c.metric, t->p.metric_k,
+                  t->d_T, c.lw, &c.st->maxabs_bits, c.N, c.k, c.k, c.metric, t->p.metric_k,
                   t->tr.d_aux_i, t->tr.d_aux_a, t->tr.d_aux_b, t->d_wmax};
         if (t->d_T == nullptr) {
             const size_t l128 = (size_t)c.k * (128 + 8) * 16 + (size_t)c.k * 24;
@@ -478,7 +478,7 @@ static int enqueue_round(rl_trainer *t)
         hipLaunchKernelGGL(k_leaf_chain, dim3(c.L), dim3(64), 0, s, c);
     } else if (t->dist) {
         // multi-GPU: gather lambda / weight in leaf order from every rank and evaluate the chains over the whole leaf
-        ChainSource src{c.lambda, c.weight, c.idx[0], c.idx[1], t->d_seg_buf};
+        ChainSource src{nullptr, nullptr, c.lw, c.idx[0], c.idx[1], t->d_seg_buf};
         const ChainBufs &lb = t->leaf_chain;
         hipLaunchKernelGGL(k_chain_prefix, dim3((unsigned)((lb.cap_tiles + 3) / 4)), dim3(kThreads), 0, s, lb, src);
         int rcd = t->dist->allgather(lb.xs, t->d_gx, (size_t)lb.A * lb.cap_n * sizeof(double), s);
@@ -488,11 +488,11 @@ static int enqueue_round(rl_trainer *t)
         hipLaunchKernelGGL(k_plan_global, dim3(1), dim3(64), 0, s, (const int32_t *)t->d_gls, t->n_ranks, t->lsstride, c.L, t->gchain);
         hipLaunchKernelGGL(k_chain_assemble, dim3(c.L, 2), dim3(kThreads), 0, s, (const double *)t->d_gx, (const int32_t *)t->d_gls, t->n_ranks, 2,
                            (int)lb.cap_n, t->lsstride, c.L, t->gchain);
-        ChainSource gsrc{t->gchain.xs, t->gchain.xs + t->gchain.cap_n, nullptr, nullptr, nullptr};
+        ChainSource gsrc{t->gchain.xs, t->gchain.xs + t->gchain.cap_n, nullptr, nullptr, nullptr, nullptr};
         enqueue_chain(t, t->gchain, gsrc);
         hipLaunchKernelGGL(k_leaf_output, dim3((c.L + kThreads - 1) / kThreads), dim3(kThreads), 0, s, c, t->gchain);
     } else {   // K7: the two Java float running sums of every leaf, exactly, in parallel (rl_chain.inc)
-        ChainSource src{c.lambda, c.weight, c.idx[0], c.idx[1], t->d_seg_buf};
+        ChainSource src{nullptr, nullptr, c.lw, c.idx[0], c.idx[1], t->d_seg_buf};
         enqueue_chain(t, t->leaf_chain, src);
         hipLaunchKernelGGL(k_leaf_output, dim3((c.L + kThreads - 1) / kThreads), dim3(kThreads), 0, s, c, t->leaf_chain);
     }
@@ -894,8 +894,8 @@ int rl_init(rl_trainer *t)
     c.feature_ids = d_fid;
 
     // ---- per-round state -------------------------------------------------------------------------
-    RL_HIP(t->pool.alloc(&c.lambda, (size_t)N)); RL_HIP(t->pool.alloc(&c.weight, (size_t)N));
-    RL_HIP(hipMemset(c.lambda, 0, (size_t)N * sizeof(double))); RL_HIP(hipMemset(c.weight, 0, (size_t)N * sizeof(double)));   // MART never writes weights (MART.java:47-51)
+    RL_HIP(t->pool.alloc(&c.lw, (size_t)N));
+    RL_HIP(hipMemset(c.lw, 0, (size_t)N * sizeof(double2)));   // MART writes zero weights (MART.java:47-51)
     RL_HIP(t->pool.alloc(&c.q, (size_t)N)); RL_HIP(t->pool.alloc(&c.r, (size_t)N));
     RL_HIP(t->pool.alloc(&c.idx[0], (size_t)N)); RL_HIP(t->pool.alloc(&c.idx[1], (size_t)N));
     RL_HIP(t->pool.alloc(&c.ql[0], (size_t)N)); RL_HIP(t->pool.alloc(&c.ql[1], (size_t)N));
@@ -919,7 +919,7 @@ int rl_init(rl_trainer *t)
     RL_HIP(t->pool.alloc(&c.leaf_node, (size_t)c.MAXN + 1)); RL_HIP(t->pool.alloc(&c.leaf_start, (size_t)c.MAXN + 2));
     RL_HIP(t->pool.alloc(&c.round_metric, (size_t)2 * t->p.n_trees));
     RL_HIP(hipMemset(c.round_metric, 0, (size_t)2 * t->p.n_trees * sizeof(float)));
-    RL_HIP(hipMemset(c.lambda, 0, N * sizeof(double))); RL_HIP(hipMemset(c.weight, 0, N * sizeof(double)));
+    RL_HIP(hipMemset(c.lw, 0, N * sizeof(double2)));
     // ensemble
     const size_t en = (size_t)t->p.n_trees * c.MAXN;
     RL_HIP(t->pool.alloc(&t->ens.feat_idx, en)); RL_HIP(t->pool.alloc(&t->ens.thr, en));
@@ -1240,8 +1240,12 @@ int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes)
     const Ctx &c = t->ctx;
     const void *src = nullptr; size_t bytes = 0;
     switch (which) {
-    case RL_ARR_LAMBDA: src = c.lambda; bytes = (size_t)c.N * 8; break;
-    case RL_ARR_WEIGHT: src = c.weight; bytes = (size_t)c.N * 8; break;
+    case RL_ARR_LAMBDA: case RL_ARR_WEIGHT: {        // interleaved on the device: strided copy of one component
+        bytes = (size_t)c.N * 8;
+        if ((int64_t)bytes > cap_bytes) return fail(RL_ERR_INVALID, "output buffer too small");
+        RL_HIP(hipMemcpy2D(out, 8, (const char *)c.lw + (which == RL_ARR_WEIGHT ? 8 : 0), 16, 8, (size_t)c.N, hipMemcpyDeviceToHost));
+        return RL_OK;
+    }
     case RL_ARR_SCORE: src = c.scores; bytes = (size_t)c.N * 8; break;
     case RL_ARR_VALID_SCORE: if (!t->has_valid) return fail(RL_ERR_STATE, "no validation set"); src = t->va.d_scores; bytes = (size_t)t->va.N * 8; break;
     case RL_ARR_NBINS: src = c.nthr; bytes = (size_t)c.F * 4; break;
@@ -1335,7 +1339,7 @@ int rl_debug_float_chain(int32_t device, const double *x, int64_t n, const int64
     RL_HIP(hipMemcpy(b.seg_start, ss.data(), ss.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     RL_HIP(hipMemcpy(b.seg_tile0, st0.data(), st0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     RL_HIP(hipMemcpy(b.plan, &plan, sizeof(plan), hipMemcpyHostToDevice));
-    ChainSource src{dx, nullptr, nullptr, nullptr, nullptr};
+    ChainSource src{dx, nullptr, nullptr, nullptr, nullptr, nullptr};
     enqueue_chain(t.get(), b, src);
     RL_HIP(hipGetLastError());
     RL_HIP(hipStreamSynchronize(t->stream));
