@@ -204,8 +204,10 @@ enum {
     RL_ARR_CHAIN_STATS = 13,    /* int32[6]: leaf float chains {evaluated, candidate-window misses repaired, finished
                                    by the serial kernel}; the same three for the per-round metric chain */
     RL_ARR_CHAIN_MISS = 14,     /* int32[2*(2*n_leaves)]: per (value array, leaf slot) window misses of the last round */
-    RL_ARR_GROW_STATS = 15      /* int32[4] cumulative: growth steps run, nodes prepared (partition + child histograms),
+    RL_ARR_GROW_STATS = 15,     /* int32[4] cumulative: growth steps run, nodes prepared (partition + child histograms),
                                    splits committed to trees, trees grown -- speculative best-first growth */
+    RL_ARR_PHASE_CLOCKS = 16    /* int64[64][16] device wall-clock stamps (10 ns) inside the last 64 growth steps; all zero unless the
+                                   library was built with -DRL_PHASE_CLOCKS (tools/phase_clocks.py) */
 };
 /* The device's two exp implementations (rho of learning/tree/LambdaMART.java:383) on n arguments: the branch-free one the
  * lambda kernels use and the literal fdlibm e_exp transcription; both must equal StrictMath.exp bit for bit. */

@@ -15,7 +15,10 @@ constexpr int kWave = 64;
 constexpr int kFinThreads = 320;     // k_hist_finish / k_hist_reduce blocks: 5 wavefronts cover the 257 bins of -tc 256 in one pass
 constexpr int kLog2Chunk = 14;       // max docs accumulated into one int64 LDS accumulator (fixes the fixed-point exponent)
 constexpr int kChunk = 1 << kLog2Chunk;   // chunk of the root histogram
-constexpr int kNodeChunk = 8192;     // largest chunk of a child-node histogram
+#ifndef RL_NODE_CHUNK
+#define RL_NODE_CHUNK 8192
+#endif
+constexpr int kNodeChunk = RL_NODE_CHUNK;     // largest chunk of a child-node histogram
 constexpr int kMinChunk = 512;       // smallest chunk a (small) node is cut into
 #ifndef RL_HIST_DOCS
 #define RL_HIST_DOCS 2
@@ -125,6 +128,7 @@ struct Ctx {
     long long *part_tot;                                               // [maxChunks] sum of q over the chunk's samples
     struct FeatBest *fb;                                               // [kSpec][2][F] per-feature best split of each new node (rl_kernels_round.inc)
     unsigned long long *fb_root;                                       // [2] exact root total of the round
+    unsigned long long *fb_sq;                                         // [kSpec] lambda^2 sum of each slot's left child (published by k_hist_finish block (0, slot))
     int32_t *tile_cnt;                                                 // [nTiles]
     long long *tile_sq;                                                // [nTiles] lambda^2 partial of each partition tile's left members
     int32_t *leaf_node, *leaf_start;                                   // [MAXN], [MAXN+1]
@@ -133,6 +137,8 @@ struct Ctx {
     // host-visible (pinned, fine-grained) growth progress: tree_seq << 32 | select_step calls in the tree << 1 | done.
     // A HINT only: the host uses it to stop enqueuing growth steps of a finished tree (extra steps are no-ops).
     unsigned long long *progress;
+    long long *clk;          // [64][16] wall-clock stamps (10 ns units) of the finish / select phases of the last 64 growth steps; only
+                             // written by builds with -DRL_PHASE_CLOCKS (tools/phase_clocks.py), RL_ARR_PHASE_CLOCKS reads it
 };
 
 void set_error(const std::string &msg);

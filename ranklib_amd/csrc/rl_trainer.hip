@@ -912,10 +912,11 @@ int rl_init(rl_trainer *t)
     RL_HIP(t->pool.alloc(&c.queue, (size_t)c.MAXN + 2));
     RL_HIP(t->pool.alloc(&c.part_sum, (size_t)c.maxChunks * F * TS)); RL_HIP(t->pool.alloc(&c.part_cnt, (size_t)c.maxChunks * F * TS));
     RL_HIP(t->pool.alloc(&c.part_tot, (size_t)std::max(c.maxChunks, (N + kMinChunk - 1) / kMinChunk) + 1));
-    RL_HIP(t->pool.alloc(&c.fb, (size_t)kSpec * 2 * F)); RL_HIP(t->pool.alloc(&c.fb_root, (size_t)2));
+    RL_HIP(t->pool.alloc(&c.fb, (size_t)kSpec * 2 * F)); RL_HIP(t->pool.alloc(&c.fb_root, (size_t)2 + kSpec)); c.fb_sq = c.fb_root + 2;
     RL_HIP(t->pool.alloc(&c.tile_cnt, (size_t)c.nTiles)); RL_HIP(t->pool.alloc(&c.tile_sq, (size_t)c.nTiles));
     RL_HIP(t->pool.alloc(&c.tile_desc, (size_t)c.nTiles)); RL_HIP(hipMemset(c.tile_desc, 0, (size_t)c.nTiles * 8));
     RL_HIP(t->pool.alloc(&c.grow_stats, (size_t)4)); RL_HIP(hipMemset(c.grow_stats, 0, 16));
+    RL_HIP(t->pool.alloc(&c.clk, (size_t)64 * 16)); RL_HIP(hipMemset(c.clk, 0, 64 * 16 * sizeof(long long)));
     RL_HIP(t->pool.alloc(&c.leaf_node, (size_t)c.MAXN + 1)); RL_HIP(t->pool.alloc(&c.leaf_start, (size_t)c.MAXN + 2));
     RL_HIP(t->pool.alloc(&c.round_metric, (size_t)2 * t->p.n_trees));
     RL_HIP(hipMemset(c.round_metric, 0, (size_t)2 * t->p.n_trees * sizeof(float)));
@@ -1254,6 +1255,7 @@ int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes)
     case RL_ARR_QUANT: src = c.q; bytes = (size_t)c.N * 8; break;
     case RL_ARR_NDCG_PER_QUERY: src = c.ndcg_q; bytes = (size_t)c.Q * 8; break;
     case RL_ARR_GROW_STATS: src = c.grow_stats; bytes = 16; break;
+    case RL_ARR_PHASE_CLOCKS: src = c.clk; bytes = 64 * 16 * sizeof(long long); break;
     case RL_ARR_CHAIN_STATS: {
         if (cap_bytes < 24) return fail(RL_ERR_INVALID, "output buffer too small");
         RL_HIP(hipMemcpy(out, (t->dist ? t->gchain : t->leaf_chain).stats, 12, hipMemcpyDeviceToHost));
