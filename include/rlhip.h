@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define RLHIP_ABI_VERSION 1
+#define RLHIP_ABI_VERSION 2
 
 enum {
     RL_OK = 0,
@@ -85,6 +85,13 @@ typedef struct {
     int32_t device;             /* HIP device ordinal */
     int32_t flags;              /* RL_FLAG_* */
     int32_t ranker;             /* RL_RANKER_LAMBDAMART (default) or RL_RANKER_MART (learning/tree/MART.java:47-65) */
+    float   feature_sampling_rate;  /* FeatureHistogram.samplingRate (learning/tree/FeatureHistogram.java:34,272-287), set by
+                                   RFRanker.init (learning/tree/RFRanker.java:68): < 1 = every split attempt looks at
+                                   (int)(rate * n_features) features drawn without replacement.  Default 1 (0 is read as 1). */
+    uint64_t seed;              /* The Java draws from an unseeded java.util.Random.  Here the draw of a node is a pure function of
+                                   (seed, index of the tree in this trainer, path of the node from the root): the features sorted by
+                                   a 64-bit hash key, the first (int)(rate * F) in key order (the first drawn wins a tie, as the
+                                   Java's scan order does).  oracle/rl_oracle.h ro_feature_order() is the same function. */
 } rl_params;
 
 /* One regression tree: nodes in pre-order (root 0, left subtree first) == Split.leaves() order

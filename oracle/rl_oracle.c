@@ -267,6 +267,7 @@ typedef struct node_s {     /* learning/tree/Split.java:22-38 */
     int32_t n;
     hist_t  *hist;
     struct node_s *left, *right;
+    uint64_t ph;            /* path hash: identifies the node for the seeded feature draw (ro_feature_order) */
 } node_t;
 
 typedef struct {            /* one data set (train or validation) */
@@ -958,8 +959,32 @@ static void hist_subtract_chunk(void *c_, int32_t fs, int32_t fe, int32_t worker
 }
 
 /* findBestSplit(usedFeatures, minLeafSupport, start, end)  :236-264 */
+/* ---- seeded stand-in for the unseeded `new Random()` of FeatureHistogram.java:283-287 ------------------------------------
+ * Drawing `size` features without replacement == taking the `size` smallest of F independent random keys, in key order. */
+static inline uint64_t mix64(uint64_t x)
+{   /* splitmix64 finaliser */
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+uint64_t ro_root_hash(uint64_t seed, int32_t tree) { return mix64(seed ^ mix64((uint64_t)(uint32_t)tree)); }
+uint64_t ro_child_hash(uint64_t parent, int32_t side) { return mix64(parent + 1u + (uint64_t)(side != 0)); }
+uint64_t ro_feature_key(uint64_t node_hash, int32_t f) { return mix64(node_hash ^ ((uint64_t)(uint32_t)(f + 1) * 0xA24BAED4963EE407ULL)); }
+int32_t ro_feature_order(uint64_t node_hash, int32_t F, float rate, int32_t *out)
+{
+    const int32_t size = (int32_t)(rate * (float)F);                    /* (int) (samplingRate * features.length)  :274 */
+    for (int32_t f = 0; f < F; f++) {
+        const uint64_t kf = ro_feature_key(node_hash, f);
+        int32_t r = 0;
+        for (int32_t g = 0; g < F; g++) { const uint64_t kg = ro_feature_key(node_hash, g); r += (kg < kf) || (kg == kf && g < f); }
+        if (r < size) out[r] = f;
+    }
+    return size;
+}
+
 typedef struct { int32_t featureIdx, thresholdIdx; double S; } cfg_t;
-typedef struct { ro_trainer *t; const hist_t *h; cfg_t cfg[1024]; } scan_ctx;
+typedef struct { ro_trainer *t; const hist_t *h; const int32_t *used; cfg_t cfg[1024]; } scan_ctx;
 static void scan_chunk(void *c_, int32_t fs, int32_t fe, int32_t worker)
 {
     scan_ctx *c = (scan_ctx *)c_;
@@ -967,9 +992,10 @@ static void scan_chunk(void *c_, int32_t fs, int32_t fe, int32_t worker)
     const hist_t *h = c->h;
     const int32_t TS = t->TS, mls = t->p.min_leaf_support;
     cfg_t cfg = { -1, -1, -1.0 };
-    const int32_t totalCount = h->count[(int64_t)fs * TS + t->nthr[fs] - 1];
+    const int32_t f0 = c->used ? c->used[fs] : fs;
+    const int32_t totalCount = h->count[(int64_t)f0 * TS + t->nthr[f0] - 1];
     for (int32_t f = fs; f <= fe; f++) {
-        const int32_t i = f;                                       /* usedFeatures[f] == f */
+        const int32_t i = c->used ? c->used[f] : f;                /* usedFeatures[f]  :289-300 */
         for (int32_t tt = 0; tt < t->nthr[i]; tt++) {
             const int32_t countLeft = h->count[(int64_t)i * TS + tt];
             const int32_t countRight = totalCount - countLeft;
@@ -1028,11 +1054,21 @@ static int node_split(ro_trainer *t, node_t *sp)
     if (sp->deviance >= 0.0 && sp->deviance <= 0.0) return 0;        /* :267-269 */
 
     scan_ctx *sc = (scan_ctx *)malloc(sizeof(scan_ctx));
-    sc->t = t; sc->h = h;
-    int32_t used = pool_run(&t->pool, t->F, scan_chunk, sc);
+    sc->t = t; sc->h = h; sc->used = NULL;
+    int32_t nused = t->F;
+    int32_t *order = NULL;
+    if (t->p.feature_sampling_rate > 0.0f && t->p.feature_sampling_rate < 1.0f) {     /* :272-287, seeded (see ro_feature_order) */
+        order = (int32_t *)malloc(sizeof(int32_t) * (size_t)t->F);
+        nused = ro_feature_order(sp->ph, t->F, t->p.feature_sampling_rate, order);
+        sc->used = order;
+    }
     cfg_t best = { -1, -1, -1.0 };
-    for (int32_t w = 0; w < used; w++)                                  /* :302-309 */
-        if (best.S < sc->cfg[w].S) best = sc->cfg[w];
+    if (nused > 0) {
+        int32_t used = pool_run(&t->pool, nused, scan_chunk, sc);
+        for (int32_t w = 0; w < used; w++)                              /* :302-309 */
+            if (best.S < sc->cfg[w].S) best = sc->cfg[w];
+    }
+    free(order);
     free(sc);
     if (best.S == -1) return 0;                                         /* :311-313 */
 
@@ -1078,6 +1114,7 @@ static int node_split(ro_trainer *t, node_t *sp)
     sp->deviance = var;
     sp->left = node_new(left, l, lh, varLeft);                          /* :353-354 */
     sp->right = node_new(right, r, rh, varRight);
+    sp->left->ph = ro_child_hash(sp->ph, 0); sp->right->ph = ro_child_hash(sp->ph, 1);
     sp->n = (int32_t)sp->n;
     /* sp.clearSamples()  :356 */
     if (!sp->isRoot) free(sp->samples);
@@ -1106,6 +1143,7 @@ static node_t *tree_fit(ro_trainer *t, int32_t *index)
     queue_t q = { NULL, 0, 0 };
     node_t *root = node_new(index, N, &t->root, (double)FLT_MAX);  /* :60 */
     root->isRoot = 1;
+    root->ph = ro_root_hash(t->p.seed, t->round);
     t->trace_n = 0;
     if (node_split(t, root)) { queue_insert(&q, root->left); queue_insert(&q, root->right); }
     int32_t taken = 0;

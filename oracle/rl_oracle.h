@@ -36,7 +36,19 @@ typedef struct {
     int32_t n_threads;        /* MyThreadPool size           utilities/MyThreadPool.java:42 */
     int32_t ranker;           /* RO_RANKER_*: 6 = LambdaMART (learning/tree/LambdaMART.java), 0 = MART (learning/tree/MART.java) */
     int32_t metric;           /* RO_METRIC_*: the train / validation metric (-metric2t), metric/MetricScorerFactory.java:24-30 */
+    float   feature_sampling_rate;  /* FeatureHistogram.samplingRate (learning/tree/FeatureHistogram.java:34,272-287): < 1 = every split
+                                       looks at (int)(rate * F) features drawn without replacement (Random Forests).  0 is read as 1. */
+    uint64_t seed;            /* the Java draws from an UNSEEDED java.util.Random; here the draw of a node is a pure function of
+                                 (seed, tree index, path of the node from the root), see ro_feature_order() */
 } ro_params;
+
+/* The feature draw of one split attempt.  `node_hash`: ro_root_hash(seed, tree) at the root, ro_child_hash(parent, side) below.
+ * out_order[0..size) = the drawn feature INDICES in draw order (the scan visits them in this order, so the first drawn wins a tie,
+ * FeatureHistogram.java:289-309): the features sorted by (ro_feature_key(node_hash, f), f), first `size`. */
+uint64_t ro_root_hash(uint64_t seed, int32_t tree);
+uint64_t ro_child_hash(uint64_t parent, int32_t side /* 0 = left, 1 = right */);
+uint64_t ro_feature_key(uint64_t node_hash, int32_t f);
+int32_t ro_feature_order(uint64_t node_hash, int32_t n_features, float rate, int32_t *out_order);
 enum { RO_RANKER_MART = 0, RO_RANKER_LAMBDAMART = 6 };
 enum { RO_METRIC_NDCG = 0, RO_METRIC_DCG = 1, RO_METRIC_MAP = 2, RO_METRIC_ERR = 3 };
 

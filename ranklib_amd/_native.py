@@ -21,7 +21,7 @@ class RlParams(C.Structure):
     _fields_ = [("n_trees", C.c_int32), ("n_leaves", C.c_int32), ("n_threshold", C.c_int32),
                 ("min_leaf_support", C.c_int32), ("early_stop_rounds", C.c_int32), ("learning_rate", C.c_float),
                 ("metric", C.c_int32), ("metric_k", C.c_int32), ("device", C.c_int32), ("flags", C.c_int32),
-                ("ranker", C.c_int32)]
+                ("ranker", C.c_int32), ("feature_sampling_rate", C.c_float), ("seed", C.c_uint64)]
 
 
 RL_METRIC = dict(NDCG=0, DCG=1, MAP=2, ERR=3)
@@ -169,13 +169,15 @@ class Trainer:
     """Thin object wrapper over the rl_trainer handle (one GPU)."""
 
     def __init__(self, n_trees=1000, n_leaves=10, learning_rate=0.1, n_threshold=256, min_leaf_support=1,
-                 early_stop_rounds=100, metric_k=10, device=0, flags=0, metric="NDCG", ranker="LAMBDAMART"):
+                 early_stop_rounds=100, metric_k=10, device=0, flags=0, metric="NDCG", ranker="LAMBDAMART",
+                 feature_sampling_rate=1.0, seed=0):
         L = lib()
         self.p = RlParams()
         L.rl_params_default(C.byref(self.p))
         self.p.n_trees, self.p.n_leaves, self.p.learning_rate = n_trees, n_leaves, learning_rate
         self.p.n_threshold, self.p.min_leaf_support, self.p.early_stop_rounds = n_threshold, min_leaf_support, early_stop_rounds
         self.p.metric_k, self.p.device, self.p.flags = metric_k, device, flags
+        self.p.feature_sampling_rate, self.p.seed = feature_sampling_rate, seed
         self.p.metric, self.p.ranker = RL_METRIC[metric.upper()], RL_RANKER[ranker.upper()]
         self.h = C.c_void_p()
         check(L.rl_create(C.byref(self.p), C.byref(self.h)))

@@ -129,6 +129,19 @@ __device__ __forceinline__ float key_float(uint32_t k)
     return __uint_as_float(u);
 }
 
+// Seeded stand-in for the unseeded `new Random()` of FeatureHistogram.java:283-287 (feature sampling of Random Forests);
+// identical to oracle/rl_oracle.c ro_root_hash / ro_child_hash / ro_feature_key.
+__host__ __device__ __forceinline__ unsigned long long mix64(unsigned long long x)
+{   // splitmix64 finaliser
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+__host__ __device__ __forceinline__ unsigned long long root_hash(unsigned long long seed, int tree) { return mix64(seed ^ mix64((unsigned long long)(unsigned)tree)); }
+__host__ __device__ __forceinline__ unsigned long long child_hash(unsigned long long parent, int side) { return mix64(parent + 1u + (unsigned long long)(side != 0)); }
+__host__ __device__ __forceinline__ unsigned long long feature_key(unsigned long long h, int f) { return mix64(h ^ ((unsigned long long)(unsigned)(f + 1) * 0xA24BAED4963EE407ULL)); }
+
 // one step of a Java `float s; s += double x;`  (LambdaMART.java:406-407)
 __device__ __forceinline__ float float_chain_step(float s, double x) { return (float)((double)s + x); }
 

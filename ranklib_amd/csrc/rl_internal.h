@@ -62,6 +62,7 @@ struct NodeRec {
     int32_t fid;             // id in the exported tree (creation order of the COMMITTED splits), -1 = not part of the tree
     int32_t prepared;
     int32_t best_cl, pad_;   // cumulative histogram entry at the best split: count ...
+    unsigned long long ph;   // path hash of the node: keys the seeded feature draw of its split attempt (rl_params.seed)
     long long best_hi; unsigned long long best_lo;   // ... and exact fixed-point sum (= the left child's totals)
 };
 
@@ -98,6 +99,8 @@ struct Ctx {
     float lr;
     int32_t rank, n_ranks;
     int32_t node_div, node_min;   // child-node histograms: target chunks per node, smallest chunk (see chunk_docs)
+    int32_t fs_size;              // features a split attempt looks at: F, or (int)(rate * F) with feature sampling (Random Forests)
+    unsigned long long seed;      // rl_params.seed
     int32_t mart, metric;    // MART leaf rule (learning/tree/MART.java); RL_METRIC_* of the train metric
     long long *dist_buf;     // [kSpec][F*TS*3 + 4] int64 limbs of the histograms being all-reduced (multi-GPU only)
     // static per data set

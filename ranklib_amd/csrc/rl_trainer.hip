@@ -419,8 +419,9 @@ static int enqueue_round(rl_trainer *t)
         launch_hist<true>(c, hist_gx, rootChunks, hist_lds, s);
     }
     // the last block of k_hist_finish runs the growth bookkeeping (select_step); node records live in LDS when they fit
-    const int nodes_in_lds = (select_lds_bytes(c.L, c.NC, true) <= 60 * 1024) ? 1 : 0;
-    const size_t fin_lds = std::max((size_t)c.TS * 20, select_lds_bytes(c.L, c.NC, nodes_in_lds != 0));
+    const int nodes_in_lds = (select_lds_bytes(c.L, c.NC, true, c.F, c.fs_size < c.F) <= 60 * 1024) ? 1 : 0;
+    const size_t fin_lds = std::max((size_t)c.TS * 20, select_lds_bytes(c.L, c.NC, nodes_in_lds != 0, c.F, c.fs_size < c.F));
+    if (fin_lds > 128 * 1024) return fail(RL_ERR_UNSUPPORTED, "too many features / leaves for the growth bookkeeping in LDS (feature sampling needs 64 bytes per feature)");
     if (t->dist) {
         hipLaunchKernelGGL(k_hist_reduce, dim3(c.F), dim3(kFinThreads), red_lds, s, c, 1);
         int rcd = t->dist->allreduce(c.dist_buf, (size_t)c.F * c.TS * 3 + 4, DT_I64, OP_SUM, s);
@@ -627,6 +628,7 @@ void rl_params_default(rl_params *p)
     p->n_trees = 1000; p->n_leaves = 10; p->n_threshold = 256; p->min_leaf_support = 1; p->early_stop_rounds = 100;
     p->learning_rate = 0.1F; p->metric = RL_METRIC_NDCG; p->metric_k = 10; p->device = 0; p->flags = 0;
     p->ranker = RL_RANKER_LAMBDAMART;
+    p->feature_sampling_rate = 1.0f; p->seed = 0;
 }
 
 int rl_create(const rl_params *p, rl_trainer **out)
@@ -638,6 +640,7 @@ int rl_create(const rl_params *p, rl_trainer **out)
     if (p->metric == RL_METRIC_MAP ? p->metric_k < 0 : p->metric_k < 1) return fail(RL_ERR_UNSUPPORTED, "metric k out of range");
     if (p->ranker != RL_RANKER_LAMBDAMART && p->ranker != RL_RANKER_MART)
         return fail(RL_ERR_UNSUPPORTED, "ranker must be RL_RANKER_LAMBDAMART (6) or RL_RANKER_MART (0)");
+    if (!(p->feature_sampling_rate >= 0.0f && p->feature_sampling_rate <= 1.0f)) return fail(RL_ERR_INVALID, "feature_sampling_rate must be in [0, 1]");
     if (p->n_trees < 1) return fail(RL_ERR_INVALID, "n_trees must be >= 1");
     if (p->n_leaves == -1) return fail(RL_ERR_UNSUPPORTED, "unlimited leaves (-leaf -1) is not built yet");
     if (p->n_leaves < 1) return fail(RL_ERR_INVALID, "n_leaves must be >= 1");
@@ -674,10 +677,10 @@ int rl_create(const rl_params *p, rl_trainer **out)
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
-    RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
-    RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
-    RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
-    RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     RL_HIP(hipFuncSetAttribute((const void *)k_rank_block, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaBlockCap * 12));
     RL_HIP(hipFuncSetAttribute((const void *)k_lambda_fused<256>, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaFusedMaxK * 256 * 16 + 2048));
     RL_HIP(hipFuncSetAttribute((const void *)k_chain_stitch, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -755,6 +758,8 @@ int rl_init(rl_trainer *t)
     c.NC = 4 * t->p.n_leaves + 2;     // node records: committed (2L-1) + prepared but never reached (see select_step)
     c.mls = t->p.min_leaf_support; c.lr = t->p.learning_rate;
     c.node_div = 12; c.node_min = kMinChunk;
+    c.fs_size = F; c.seed = t->p.seed;
+    if (t->p.feature_sampling_rate > 0.0f && t->p.feature_sampling_rate < 1.0f) c.fs_size = (int32_t)(t->p.feature_sampling_rate * (float)F);   // :274
     if (const char *e = getenv("RLHIP_NODE_DIV")) c.node_div = std::max(1, atoi(e));          // tuning knobs (tools/), not API
     if (const char *e = getenv("RLHIP_NODE_MIN")) c.node_min = std::max(256, atoi(e) & ~255);
     c.metric = t->p.metric; c.mart = (t->p.ranker == RL_RANKER_MART) ? 1 : 0;

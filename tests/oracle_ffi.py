@@ -13,7 +13,8 @@ _SO = os.path.join(_ORACLE_DIR, "librl_oracle.so")
 class RoParams(C.Structure):
     _fields_ = [("n_trees", C.c_int32), ("n_leaves", C.c_int32), ("n_threshold", C.c_int32),
                 ("min_leaf_support", C.c_int32), ("early_stop", C.c_int32), ("learning_rate", C.c_float),
-                ("metric_k", C.c_int32), ("n_threads", C.c_int32), ("ranker", C.c_int32), ("metric", C.c_int32)]
+                ("metric_k", C.c_int32), ("n_threads", C.c_int32), ("ranker", C.c_int32), ("metric", C.c_int32),
+                ("feature_sampling_rate", C.c_float), ("seed", C.c_uint64)]
 
 
 RANKER = dict(MART=0, LAMBDAMART=6)
@@ -51,6 +52,10 @@ def lib():
         L.ro_set_validation.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
                                         C.c_void_p]
         L.ro_destroy.argtypes = [C.c_void_p]
+        L.ro_root_hash.restype = C.c_uint64; L.ro_root_hash.argtypes = [C.c_uint64, C.c_int32]
+        L.ro_child_hash.restype = C.c_uint64; L.ro_child_hash.argtypes = [C.c_uint64, C.c_int32]
+        L.ro_feature_key.restype = C.c_uint64; L.ro_feature_key.argtypes = [C.c_uint64, C.c_int32]
+        L.ro_feature_order.restype = C.c_int32; L.ro_feature_order.argtypes = [C.c_uint64, C.c_int32, C.c_float, C.c_void_p]
         L.ro_init.argtypes = [C.c_void_p]
         L.ro_round.restype = C.c_int
         L.ro_round.argtypes = [C.c_void_p, C.POINTER(RoTree), C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -125,14 +130,14 @@ class Tree:
 class Oracle:
     def __init__(self, X, labels, qoff, n_trees=10, n_leaves=10, lr=0.1, n_threshold=256, mls=1, k=10,
                  early_stop=100, n_threads=1, feature_ids=None, qkey=None, max_nodes=None, ranker="LAMBDAMART",
-                 metric="NDCG"):
+                 metric="NDCG", frate=1.0, seed=0):
         self.L = lib()
         self.X = np.ascontiguousarray(X, dtype=np.float32)
         self.labels = np.ascontiguousarray(labels, dtype=np.float32)
         self.qoff = np.ascontiguousarray(qoff, dtype=np.int32)
         self.N, self.F = self.X.shape
         self.Q = len(self.qoff) - 1
-        self.p = RoParams(n_trees, n_leaves, n_threshold, mls, early_stop, lr, k, n_threads, RANKER[ranker], METRIC[metric])
+        self.p = RoParams(n_trees, n_leaves, n_threshold, mls, early_stop, lr, k, n_threads, RANKER[ranker], METRIC[metric], frate, seed)
         fid = None if feature_ids is None else np.ascontiguousarray(feature_ids, dtype=np.int32)
         qk = None if qkey is None else np.ascontiguousarray(qkey, dtype=np.int32)
         self._keep = (fid, qk)
@@ -281,6 +286,12 @@ def sort_desc(scores):
     idx = np.zeros(len(s), np.int32)
     lib().ro_sort_desc(s.ctypes.data, len(s), idx.ctypes.data)
     return idx
+
+
+def feature_order(node_hash, n_features, rate):
+    out = np.zeros(n_features, np.int32)
+    n = lib().ro_feature_order(node_hash, n_features, rate, out.ctypes.data)
+    return out[:n]
 
 
 def float_chain(x, idx=None):

@@ -356,6 +356,42 @@ def test_other_rankers_and_metrics_match_the_oracle(ranker, metric, k, kind, see
     assert text.startswith("## %s\n" % ("MART" if ranker == "MART" else "LambdaMART"))
 
 
+# ---- feature sampling of Random Forests (FeatureHistogram.samplingRate), seeded ------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranker,frate,n_feat,leaves,seed", [
+    ("MART", 0.3, 12, 8, 1), ("MART", 0.3, 136, 20, 2), ("LAMBDAMART", 0.5, 12, 8, 3), ("LAMBDAMART", 0.3, 40, 31, 4),
+    ("MART", 0.05, 12, 8, 5), ("MART", 0.999, 12, 8, 6)])
+def test_feature_sampling_matches_the_oracle(ranker, frate, n_feat, leaves, seed):
+    """every split attempt looks at (int)(rate * F) features drawn by the seeded hash of (seed, tree, node path); the first drawn
+    wins a tie (FeatureHistogram.java:272-309).  rate 0.05 * 12 features = 0 features: single-leaf trees."""
+    X, lab, qoff = synth.make_dataset(4000, n_feat, "mslr", seed_offset=70 + seed)
+    rounds = 4
+    o = O.Oracle(X, lab, qoff, n_trees=rounds, n_leaves=leaves, ranker=ranker, n_threads=3, frate=frate, seed=1000 + seed)
+    g = N.Trainer(n_trees=rounds, n_leaves=leaves, ranker=ranker, feature_sampling_rate=frate, seed=1000 + seed)
+    g.set_train(X, lab, qoff)
+    o.init(); g.init()
+    used = set()
+    for m in range(rounds):
+        to, tmo, _, _ = o.round()
+        tg, tmg, _, _ = g.boost_round()
+        assert_equivalent(to, tg, X, ctx="round %d" % m)
+        assert np.array_equal(g.array("SCORE"), o.scores()), "scores mismatch in round %d" % m
+        assert np.float32(tmg) == np.float32(tmo)
+        used |= set(tg.trimmed()["feature"].tolist())
+    if frate == 0.05:
+        assert used == {-1}
+    # the draw really differs from "all features": a different seed grows different trees
+    if 0.1 < frate < 0.9:
+        g2 = N.Trainer(n_trees=1, n_leaves=leaves, ranker=ranker, feature_sampling_rate=frate, seed=5)
+        g2.set_train(X, lab, qoff); g2.init()
+        t2, _, _, _ = g2.boost_round()
+        g3 = N.Trainer(n_trees=1, n_leaves=leaves, ranker=ranker, feature_sampling_rate=frate, seed=6)
+        g3.set_train(X, lab, qoff); g3.init()
+        t3, _, _, _ = g3.boost_round()
+        assert not np.array_equal(t2.trimmed()["feature"], t3.trimmed()["feature"]) or \
+            not np.array_equal(t2.trimmed()["threshold"], t3.trimmed()["threshold"])
+
+
 # ---- SURVEY.md 8f-1: Ensemble.eval at scale (LDS-tiled kernel, packed nodes) ------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_feat,leaves,rounds", [(136, 31, 37), (20, 10, 16), (12, 150, 3)])
