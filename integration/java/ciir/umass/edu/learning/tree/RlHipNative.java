@@ -8,7 +8,7 @@ final class RlHipNative {
     private RlHipNative() {}
     /** metric: 0 NDCG, 1 DCG, 2 MAP, 3 ERR (RL_METRIC_*); ranker: 6 LambdaMART, 0 MART (RL_RANKER_*) */
     static native long create(int nTrees, int nLeaves, int nThreshold, int minLeafSupport, int stopEarly, float lr, int metric, int k,
-            int ranker, int device);
+            int ranker, int device, float featureSamplingRate, long seed);
     static native void destroy(long h);
     static native int setData(long h, boolean validation, FloatBuffer X, long nDocs, int nFeatures, float[] labels, int[] qoff,
             int[] featureIds, int[] qkey);

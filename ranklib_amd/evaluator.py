@@ -9,7 +9,8 @@ import sys
 
 from ._native import RankLibError
 from .features import FeatureManager
-from .learning import DataPoint, LambdaMART, RankerFactory, RankerTrainer, RankerType, java_round, stable_desc_order
+from .learning import (DataPoint, FeatureHistogram, LambdaMART, RankerFactory, RankerTrainer, RankerType, RFRanker, java_round,
+                       stable_desc_order)
 from .metric import MetricScorerFactory
 
 logger = logging.getLogger("ranklib_amd")
@@ -135,7 +136,7 @@ def main(argv=None):
     args = list(sys.argv[1:] if argv is None else argv)
     logging.basicConfig(level=logging.INFO, format="%(message)s")
     if not args:
-        print("Usage: -train <file> -ranker 6|0 [-metric2t NDCG@k|DCG@k|MAP|ERR@k] [-tree n] [-leaf n] [-shrinkage f] [-tc n] [-mls n] [-estop n] "
+        print("Usage: -train <file> -ranker 6|0|8 [-bag n -srate f -frate f -rtype 0|6 -seed n] [-metric2t NDCG@k|DCG@k|MAP|ERR@k] [-tree n] [-leaf n] [-shrinkage f] [-tc n] [-mls n] [-estop n] "
               "[-validate f] [-test f] [-feature f] [-save model] | -load model [-test f] [-rank f -indri out] [-score out]")
         return 0
     trainFile = validationFile = testFile = featureDescriptionFile = savedModelFile = rankFile = indriRankingFile = scoreFile = modelFile = ""
@@ -167,22 +168,31 @@ def main(argv=None):
         elif a == "-indri": indriRankingFile = nxt()
         elif a == "-missingzero": DataPoint.missingZero = True
         elif a == "-sparse": pass                           # row storage only (:268-269)
-        elif a == "-tree": LambdaMART.nTrees = int(nxt())
-        elif a == "-leaf": LambdaMART.nTreeLeaves = int(nxt())
-        elif a == "-shrinkage": LambdaMART.learningRate = float(nxt())
-        elif a == "-tc": LambdaMART.nThreshold = int(nxt())
-        elif a == "-mls": LambdaMART.minLeafSupport = int(nxt())
+        elif a == "-tree": LambdaMART.nTrees = RFRanker.nTrees = int(nxt())                 # :326-337: both sets of statics
+        elif a == "-leaf": LambdaMART.nTreeLeaves = RFRanker.nTreeLeaves = int(nxt())
+        elif a == "-shrinkage": LambdaMART.learningRate = RFRanker.learningRate = float(nxt())
+        elif a == "-tc": LambdaMART.nThreshold = int(nxt())                                  # :300-303: NOT RFRanker.nThreshold
+        elif a == "-mls": LambdaMART.minLeafSupport = RFRanker.minLeafSupport = int(nxt())
         elif a == "-estop": LambdaMART.nRoundToStopEarly = int(nxt())
+        elif a == "-bag": RFRanker.nBag = int(nxt())                                         # :340-352
+        elif a == "-srate": RFRanker.subSamplingRate = float(nxt())
+        elif a == "-frate": RFRanker.featureSamplingRate = float(nxt())
+        elif a == "-rtype":
+            rt = int(nxt())
+            if rt not in (0, 6):
+                raise RankLibError("%s cannot be bagged. Random Forests only supports MART/LambdaMART." % rt)
+            RFRanker.rType = RankerType(rt)
+        elif a == "-seed": RFRanker.seed = FeatureHistogram.seed = int(nxt())               # rlhip extension: the Java draws are unseeded
         elif a == "-thread": nxt()                          # CPU thread pool of the reference: irrelevant here
         elif a == "-tts": ttSplit = float(nxt())            # :245-250
         elif a == "-tvs": tvSplit = float(nxt())
         elif a == "-kcv": foldCV = int(nxt())
         elif a == "-kcvmd": kcvModelDir = nxt()
         elif a == "-kcvmn": kcvModelFile = nxt()
-        elif a in ("-frate", "-srate", "-bag", "-round", "-epoch", "-tolerance", "-reg", "-r", "-i", "-norm",
-                   "-layer", "-node", "-lr", "-noeq", "-max", "-rtype", "-l2"):
+        elif a in ("-round", "-epoch", "-tolerance", "-reg", "-r", "-i", "-norm",
+                   "-layer", "-node", "-lr", "-noeq", "-max", "-l2"):
             # parameters of the other rankers / of flows that are out of scope: parsed (the reference's own test passes
-            # -frate -bag -round -epoch to every ranker, test:eval/EvaluatorTest.java:207-220) and ignored
+            # -round -epoch to every ranker, test:eval/EvaluatorTest.java:207-220) and ignored
             if a != "-noeq":
                 nxt()
         elif a == "-device": LambdaMART.device = int(nxt())
@@ -191,9 +201,9 @@ def main(argv=None):
         i += 1
     if not testMetric:
         testMetric = trainMetric                            # :379-381
-    if trainFile and rankerType not in (0, 6):
-        raise RankLibError("rlhip builds -ranker 6 (LambdaMART) and -ranker 0 (MART) only")
-    e = Evaluator(RankerType(rankerType) if rankerType in (0, 6) else RankerType.LAMBDAMART, trainMetric, testMetric)
+    if trainFile and rankerType not in (0, 6, 8):
+        raise RankLibError("rlhip builds -ranker 6 (LambdaMART), -ranker 0 (MART) and -ranker 8 (Random Forests) only")
+    e = Evaluator(RankerType(rankerType) if rankerType in (0, 6, 8) else RankerType.LAMBDAMART, trainMetric, testMetric)
     if trainFile:
         if foldCV != -1:                                    # :469-482
             if kcvModelDir and not kcvModelFile:

@@ -15,6 +15,7 @@ All numeric work happens behind the C ABI (ranklib_amd/_native.py); nothing here
 lambda or a tree on the CPU.
 """
 import enum
+import random
 import logging
 import math
 import time
@@ -244,6 +245,13 @@ def java_round(val, n):               # utilities/SimpleMath.java:54-60
     return math.floor(val * p + .5) / p
 
 
+class FeatureHistogram:
+    """Only the process-global knob of learning/tree/FeatureHistogram.java:34 lives on the host: the fraction of the features
+    every split attempt looks at (set by RFRanker.init, never restored -- like the Java static)."""
+    samplingRate = 1.0
+    seed = 0          # not in the Java (it draws from an unseeded Random): makes the draw reproducible, see rlhip.h rl_params.seed
+
+
 class LambdaMART(Ranker):
     """learning/tree/LambdaMART.java with init()/learn() executed on an MI355X (librlhip.so)."""
     # process-global parameters, like the Java statics (:37-42)
@@ -275,7 +283,8 @@ class LambdaMART(Ranker):
         nk = int(qkey.max()) + 1 if len(qkey) else 0
         t = N.Trainer(n_trees=cls.nTrees, n_leaves=cls.nTreeLeaves, learning_rate=cls.learningRate, n_threshold=cls.nThreshold,
                       min_leaf_support=cls.minLeafSupport, early_stop_rounds=cls.nRoundToStopEarly, metric_k=self.scorer.getK(),
-                      device=cls.device, metric=metric, ranker=self._RANKER)
+                      device=cls.device, metric=metric, ranker=self._RANKER,
+                      feature_sampling_rate=FeatureHistogram.samplingRate, seed=FeatureHistogram.seed)
         t.set_train(X, lab, qoff, feature_ids=self.features, qkey=qkey)
         if self.validationSamples is not None:
             Xv, lv, qv, _ = flatten(self.validationSamples, self.features)
@@ -381,6 +390,204 @@ class MART(LambdaMART):
         return "MART"
 
 
+def java_float_str(v):
+    """Float.toString of a Java float (header lines of the model files): shortest digits that round-trip, decimal notation for
+    1e-3 <= |v| < 1e7, computerised scientific notation otherwise."""
+    f = np.float32(v)
+    if f == 0:
+        return "-0.0" if np.signbit(f) else "0.0"
+    a = abs(float(f))
+    if 1e-3 <= a < 1e7:
+        r = np.format_float_positional(f, unique=True, trim="0")
+        return r if "." in r else r + ".0"
+    m, e = np.format_float_scientific(f, unique=True, trim="0").split("e")
+    return (m if "." in m else m + ".0") + "E" + str(int(e))
+
+
+class Sampler:
+    """learning/Sampler.java:25-68.  The Java draws from an unseeded java.util.Random; `seed` makes the bags reproducible."""
+
+    def __init__(self, seed=None):
+        self.rng = random.Random(seed)
+        self.samples = None
+        self.remains = None
+
+    def doSampling(self, samplingPool, samplingRate, withReplacement):
+        n = len(samplingPool)
+        size = int(np.float32(samplingRate) * np.float32(n))          # (int) (samplingRate * samplingPool.size()), float arithmetic
+        self.samples = []
+        if withReplacement:
+            used = [False] * n
+            for _ in range(size):
+                sel = self.rng.randrange(n)
+                self.samples.append(samplingPool[sel])
+                used[sel] = True
+            self.remains = [samplingPool[i] for i in range(n) if not used[i]]
+        else:
+            pool = list(range(n))
+            for _ in range(size):
+                sel = self.rng.randrange(len(pool))
+                self.samples.append(samplingPool[pool[sel]])
+                del pool[sel]
+            self.remains = [samplingPool[i] for i in pool]
+        return self.samples
+
+    def getSamples(self):
+        return self.samples
+
+    def getRemains(self):
+        return self.remains
+
+
+class RFRanker(Ranker):
+    """learning/tree/RFRanker.java: bagging over MART / LambdaMART trained on the GPU.  Every bag is a sample of the training
+    lists WITH replacement (Sampler), trained with feature sampling at every split attempt (FeatureHistogram.samplingRate);
+    eval = mean over the bags of Ensemble.eval (:109-115)."""
+    nBag = 300
+    subSamplingRate = 1.0
+    featureSamplingRate = 0.3
+    rType = None                      # RankerType.MART, set below (the enum is defined after this class)
+    nTrees = 1
+    nTreeLeaves = 100
+    learningRate = 0.1
+    nThreshold = 256
+    minLeafSupport = 1
+    seed = 0                          # not in the Java: bag i samples with Random(mix(seed, i)) and draws features with the same seed
+
+    def __init__(self, samples=None, features=None, scorer=None):
+        super().__init__(samples, features, scorer)
+        self.ensembles = None         # per bag: the "<ensemble>...</ensemble>\n" text (Ensemble.toString)
+        self._models = None           # per bag: N.Model for scoring
+
+    @staticmethod
+    def bag_seed(seed, i):
+        return (int(seed) * 0x9E3779B97F4A7C15 + (i + 1) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+    def init(self):                   # :57-69 -- overwrites LambdaMART's statics and never restores them, like the Java
+        logger.info("Initializing... ")
+        cls = type(self)
+        self.ensembles = [None] * cls.nBag
+        LambdaMART.nTrees = cls.nTrees
+        LambdaMART.nTreeLeaves = cls.nTreeLeaves
+        LambdaMART.learningRate = cls.learningRate
+        LambdaMART.nThreshold = cls.nThreshold
+        LambdaMART.minLeafSupport = cls.minLeafSupport
+        LambdaMART.nRoundToStopEarly = -1          # no early stopping inside a bag
+        FeatureHistogram.samplingRate = cls.featureSamplingRate
+
+    def learn(self):                  # :72-107
+        cls = type(self)
+        rf = RankerFactory()
+        logger.info("Training starts...")
+        nm = self.scorer.name()
+        self.printLogLn([9, 9, 11], ["bag", nm + "-B", nm + "-OOB"])
+        impacts = None
+        self._models = []
+        for i in range(cls.nBag):
+            bs = self.bag_seed(cls.seed, i)
+            sp = Sampler(bs)
+            bag = sp.doSampling(self.samples, cls.subSamplingRate, True)
+            FeatureHistogram.seed = bs
+            r = rf.createRanker(cls.rType, bag, self.features, self.scorer)
+            r.init()
+            r.learn()
+            impacts = r.impacts if impacts is None else impacts + r.impacts
+            self.printLogLn([9, 9], ["b[%d]" % (i + 1), repr(java_round(r.getScoreOnTrainingData(), 4))])
+            self.ensembles[i] = r.toString()
+            self._models.append(r._model)
+        self.scoreOnTrainingData = self.scorer.score(self.rank(self.samples))
+        logger.info("Finished sucessfully.")
+        logger.info("%s on training data: %s", nm, java_round(self.scoreOnTrainingData, 4))
+        if self.validationSamples is not None:
+            self.bestScoreOnValidationData = self.scorer.score(self.rank(self.validationSamples))
+            logger.info("%s on validation data: %s", nm, java_round(self.bestScoreOnValidationData, 4))
+        logger.info("-- FEATURE IMPACTS")
+        for i, f in enumerate(self.features):
+            logger.info(" Feature %d reduced error %s", f, impacts[i])
+
+    def _rows(self, dps):
+        need = max(int(max(m.features(), default=0)) for m in self._models)
+        width = max([need + 1] + [len(dp.fVals) for dp in dps])
+        rows = np.zeros((len(dps), width), np.float32)
+        for i, dp in enumerate(dps):
+            fv = dp.fVals
+            rows[i, :len(fv)] = np.where(np.isnan(fv), np.float32(0), fv)
+        if not DataPoint.missingZero:
+            for dp in dps:
+                if need >= len(dp.fVals):
+                    raise RankLibError("Error in DenseDataPoint::getFeatureValue(): requesting unspecified feature, fid=%d" % need)
+        return rows
+
+    def evalList(self, rl):           # :109-115 for every document of the list: double s += (float) ensemble.eval; s / nBag
+        rows = self._rows(rl.rl)
+        s = np.zeros(len(rows), np.float64)
+        for m in self._models:
+            s += m.predict_rows(rows).astype(np.float64)
+        return [float(v) for v in s / len(self._models)]
+
+    def eval(self, dp):               # noqa: A003
+        return self.evalList(RankList([dp]))[0]
+
+    def createNew(self):
+        return RFRanker()
+
+    def toString(self):               # :122-128
+        return "".join(e + "\n" for e in self.ensembles)
+
+    def model(self):                  # :131-143
+        cls = type(self)
+        out = "## " + self.name() + "\n"
+        out += "## No. of bags = %d\n" % cls.nBag
+        out += "## Sub-sampling = %s\n" % java_float_str(cls.subSamplingRate)
+        out += "## Feature-sampling = %s\n" % java_float_str(cls.featureSamplingRate)
+        out += "## No. of trees = %d\n" % cls.nTrees
+        out += "## No. of leaves = %d\n" % cls.nTreeLeaves
+        out += "## No. of threshold candidates = %d\n" % cls.nThreshold
+        out += "## Learning rate = %s\n" % java_float_str(cls.learningRate)
+        out += "\n"
+        return out + self.toString()
+
+    def loadFromString(self, fullText):   # :146-178: every "<ensemble> ... </ensemble>" block is one bag
+        text = "\n".join(ln for ln in fullText.split("\n") if not ln.startswith("##"))       # parsing/ModelLineProducer.java:43-78
+        blocks = []
+        pos = 0
+        while True:
+            a = text.find("<ensemble>", pos)
+            if a < 0:
+                break
+            b = text.find("</ensemble>", a)
+            if b < 0:
+                raise RankLibError("Error in RFRanker::load(): unterminated <ensemble>")
+            blocks.append(text[a:b + len("</ensemble>")])
+            pos = b + len("</ensemble>")
+        if not blocks:
+            raise RankLibError("Error in RFRanker::load(): no <ensemble> in the model")
+        self.ensembles = [blk + "\n" for blk in blocks]
+        self._models = [N.Model("## LambdaMART\n\n" + blk + "\n", LambdaMART.device) for blk in blocks]
+        feats = []
+        for m in self._models:                  # insertion-ordered set (the Java uses a HashSet: iteration order unspecified)
+            for f in m.features():
+                if int(f) not in feats:
+                    feats.append(int(f))
+        self.features = feats
+
+    def name(self):
+        return "Random Forests"
+
+    def getEnsembles(self):
+        return self.ensembles
+
+    def printParameters(self):        # :181-189
+        cls = type(self)
+        logger.info("No. of bags: %d", cls.nBag)
+        logger.info("Sub-sampling: %s", java_float_str(cls.subSamplingRate))
+        logger.info("Feature-sampling: %s", java_float_str(cls.featureSamplingRate))
+        logger.info("No. of trees: %d", cls.nTrees)
+        logger.info("No. of leaves: %d", cls.nTreeLeaves)
+        logger.info("No. of threshold candidates: %d", cls.nThreshold)
+        logger.info("Learning rate: %s", java_float_str(cls.learningRate))
+
+
 # ---------------------------------------------------------------------------------------------------------
 class RankerType(enum.Enum):          # learning/RankerType.java
     MART = 0
@@ -395,9 +602,13 @@ class RankerType(enum.Enum):          # learning/RankerType.java
     LINEAR_REGRESSION = 9
 
 
+RFRanker.rType = RankerType.MART
+
+
 class RankerFactory:                  # learning/RankerFactory.java:36-118
     def __init__(self):
-        self.map = {"LAMBDAMART": LambdaMART, "MART": MART}
+        self.map = {"LAMBDAMART": LambdaMART, "MART": MART, "RANDOM_FOREST": RFRanker}
+        self.names = {"LAMBDAMART": "LAMBDAMART", "MART": "MART", "RANDOM FORESTS": "RANDOM_FOREST"}     # name().toUpperCase() -> type (:44-53)
 
     def createRanker(self, rtype, samples=None, features=None, scorer=None):
         if isinstance(rtype, str):
@@ -406,7 +617,7 @@ class RankerFactory:                  # learning/RankerFactory.java:36-118
             except KeyError:
                 raise RankLibError("Could find the class \"%s\" you specified. Make sure the jar library is in your classpath." % rtype)
         if rtype.name not in self.map:
-            raise RankLibError("rlhip builds -ranker 6 (LambdaMART) and -ranker 0 (MART) only; %s is out of scope (SURVEY.md 8)" % rtype.name)
+            raise RankLibError("rlhip builds -ranker 6 (LambdaMART), 0 (MART) and 8 (Random Forests) only; %s is out of scope (SURVEY.md 8)" % rtype.name)
         r = self.map[rtype.name]()
         if samples is not None:
             r.setTrainingSet(samples)
@@ -417,9 +628,9 @@ class RankerFactory:                  # learning/RankerFactory.java:36-118
     def loadRankerFromString(self, fullText):      # :108-118: the first line names the algorithm
         first = fullText.split("\n", 1)[0]
         name = first.replace("## ", "").strip()
-        if name.upper() not in self.map:
-            raise RankLibError("Model file does not start with '## LambdaMART' or '## MART' (got %r)" % first)
-        r = self.createRanker(RankerType[name.upper()])
+        if name.upper() not in self.names:
+            raise RankLibError("Model file does not start with '## LambdaMART', '## MART' or '## Random Forests' (got %r)" % first)
+        r = self.createRanker(RankerType[self.names[name.upper()]])
         r.loadFromString(fullText)
         return r
 
