@@ -1421,21 +1421,23 @@ __global__ __launch_bounds__(kThreads) void k_model_eval(const EnsTree e, const 
 //       bits 0..31 threshold (or leaf output) float bits | 32..47 byte offset of the column in sX (0xFFFF = leaf)
 //       | 48..63 byte offset of the left child in the tree
 //     so a step is: load node, load value, compare, add -- 7 VALU + 2 LDS instructions;
-//   * wavefront p of the block walks trees [p*kEvalIlp, (p+1)*kEvalIlp) of the tile for all documents, kEvalIlp
-//     independent chains per lane (a leaf is a fixed point of the step, so finished trees idle in place), and leaves the
-//     leaf outputs in LDS; wavefront 0 then adds them in tree order, s = (float)(s + out * weight), exactly as
-//     Ensemble.eval does (learning/tree/Ensemble.java:110-116).  Splitting the TREES of a tile over the wavefronts
-//     (instead of giving every wavefront its own documents) keeps the LDS copy of a document shared by four
-//     wavefronts: 8 wavefronts per CU instead of 4 -- the kernel is latency-bound otherwise;
+//   * walker wavefront p (of kEvalParts) owns trees [p*kEvalPer, (p+1)*kEvalPer) of the tile for all documents: kEvalPer
+//     chains per lane in lockstep (a leaf is a fixed point of the step, so finished trees idle in place).  The walk is
+//     bound by instruction issue (13 per chain step), not by LDS latency.  Measured and dropped: refilling a finished chain
+//     with the lane's next tree (fewer steps, but a leaf branch that some lane takes at almost every step: 8.2 M docs/s
+//     against 14.8), and a branch-free step with all value loads issued first (22 instructions per step: 9.7 M docs/s);
+//   * one more wavefront does nothing but Ensemble.eval's accumulation  s = (float)(s + out * weight)  in tree order
+//     (learning/tree/Ensemble.java:110-116) for the PREVIOUS tile (leaf outputs double-buffered in LDS), so the serial
+//     float chain of a document overlaps the walk of the next tile instead of stalling the walkers;
 //   * the next tile of trees is fetched into registers while the current one is walked.
 // Needs: column offsets and child offsets that fit 16 bits, and the LDS budget; otherwise k_model_eval runs.
 // ------------------------------------------------------------------------------------------------
-constexpr int kEvalDocs = 64, kEvalParts = 4, kEvalIlp = 8, kEvalTreeTile = kEvalParts * kEvalIlp;
-constexpr int kEvalThreads = kEvalDocs * kEvalParts, kEvalPrefetch = 8;     // 8-byte words each thread prefetches per tile
+constexpr int kEvalDocs = 64, kEvalParts = 4, kEvalPer = 8, kEvalTreeTile = kEvalParts * kEvalPer;
+constexpr int kEvalThreads = kEvalDocs * (kEvalParts + 1), kEvalPrefetch = 8;     // 8-byte words each thread prefetches per tile
 
 static inline size_t eval_tiled_lds(int cols, int maxn)
 {
-    return (size_t)cols * kEvalDocs * 4 + (size_t)kEvalTreeTile * maxn * 8 + (size_t)kEvalTreeTile * kEvalDocs * 4 + kEvalTreeTile * 4;
+    return (size_t)cols * kEvalDocs * 4 + (size_t)kEvalTreeTile * maxn * 8 + (size_t)2 * kEvalTreeTile * kEvalDocs * 4 + 2 * kEvalTreeTile * 4;
 }
 
 // cols = max(row_stride, largest column any node reads + 1)
@@ -1445,9 +1447,10 @@ __global__ __launch_bounds__(kEvalThreads) void k_model_eval_tiled(const unsigne
     extern __shared__ unsigned char ev_raw[];
     float *sX = (float *)ev_raw;                                               // [cols][kEvalDocs]
     unsigned long long *sT = (unsigned long long *)(sX + (size_t)cols * kEvalDocs);   // [kEvalTreeTile][MAXN]
-    float *sO = (float *)(sT + (size_t)kEvalTreeTile * MAXN);                  // [kEvalTreeTile][kEvalDocs] leaf outputs
-    float *sW = sO + kEvalTreeTile * kEvalDocs;                                // [kEvalTreeTile] tree weights
+    float *sO = (float *)(sT + (size_t)kEvalTreeTile * MAXN);                  // [2][kEvalTreeTile][kEvalDocs] leaf outputs (double buffer)
+    float *sW = sO + 2 * kEvalTreeTile * kEvalDocs;                            // [2][kEvalTreeTile] tree weights
     const int tid = threadIdx.x, doc = tid & (kEvalDocs - 1), part = tid / kEvalDocs;
+    const bool walker = part < kEvalParts;
     const int tile_words = kEvalTreeTile * MAXN;                               // <= kEvalThreads * kEvalPrefetch (checked by the host)
     const unsigned char *sXb = (const unsigned char *)sX + doc * 4;
     for (int64_t tile = blockIdx.x; tile * kEvalDocs < n; tile += gridDim.x) {
@@ -1457,16 +1460,18 @@ __global__ __launch_bounds__(kEvalThreads) void k_model_eval_tiled(const unsigne
         const float *src = X + (size_t)d0 * stride;                            // the tile is one contiguous range of X
         for (int e = tid; e < nd * stride; e += kEvalThreads) { const int dd = e / stride, c = e - dd * stride; sX[c * kEvalDocs + dd] = src[e]; }
         for (int e = tid; e < (cols - stride) * kEvalDocs; e += kEvalThreads) sX[stride * kEvalDocs + e] = 0.f;
-        float s = 0.f;
+        float s = 0.f;                                                         // the accumulator wavefront's running Ensemble.eval sum
         unsigned long long pre[kEvalPrefetch];
 #pragma unroll
         for (int u = 0; u < kEvalPrefetch; u++) { const int e = tid + u * kEvalThreads; pre[u] = (e < min(tile_words, nt * MAXN)) ? nodes[e] : 0ull; }
-        for (int t0 = 0; t0 < nt; t0 += kEvalTreeTile) {
+        int k = 0, tt_prev = 0;
+        for (int t0 = 0; t0 < nt; t0 += kEvalTreeTile, k++) {
             const int tt = min(kEvalTreeTile, nt - t0);
-            __syncthreads();
+            const int cb = k & 1;
+            __syncthreads();                                                   // tile k-1 walked (its outputs complete), sT free
 #pragma unroll
             for (int u = 0; u < kEvalPrefetch; u++) { const int e = tid + u * kEvalThreads; if (e < tile_words) sT[e] = pre[u]; }
-            if (tid < tt) sW[tid] = w[t0 + tid];
+            if (tid < tt) sW[cb * kEvalTreeTile + tid] = w[t0 + tid];
             __syncthreads();
             {   // next tile -> registers (in flight during the walk)
                 const size_t nb = (size_t)(t0 + kEvalTreeTile) * MAXN;
@@ -1474,34 +1479,47 @@ __global__ __launch_bounds__(kEvalThreads) void k_model_eval_tiled(const unsigne
 #pragma unroll
                 for (int u = 0; u < kEvalPrefetch; u++) { const int e = tid + u * kEvalThreads; pre[u] = (e < tile_words && e < left) ? nodes[nb + e] : 0ull; }
             }
-            const int g = part * kEvalIlp;
-            if (doc < nd && g < tt) {
-                const unsigned char *tb[kEvalIlp];
-                unsigned long long v[kEvalIlp];
+            if (walker) {
+                const int g = part * kEvalPer;
+                const int cnt = min(kEvalPer, tt - g);                         // trees of this wavefront in the tile (<= 0: none)
+                if (doc < nd && cnt > 0) {      // kEvalPer chains per lane in lockstep; a chain whose lanes are all on leaves is skipped (execz)
+                    float *so = sO + (size_t)cb * kEvalTreeTile * kEvalDocs + (size_t)g * kEvalDocs + doc;
+                    const unsigned char *tb[kEvalPer];
+                    unsigned long long v[kEvalPer];
 #pragma unroll
-                for (int u = 0; u < kEvalIlp; u++) { tb[u] = (const unsigned char *)(sT + min(g + u, tt - 1) * MAXN); v[u] = *(const unsigned long long *)tb[u]; }
-                bool any = true;
-                while (any) {
-                    any = false;
+                    for (int u = 0; u < kEvalPer; u++) { tb[u] = (const unsigned char *)(sT + (size_t)(g + min(u, cnt - 1)) * MAXN); v[u] = *(const unsigned long long *)tb[u]; }
+                    bool any = true;
+                    while (any) {
+                        any = false;
 #pragma unroll
-                    for (int u = 0; u < kEvalIlp; u++) {
-                        const unsigned hi = (unsigned)(v[u] >> 32), co = hi & 0xffffu;
-                        if (co != 0xffffu) {                                   // Split.eval: value <= threshold goes left (Split.java:118)
-                            const float x = *(const float *)(sXb + co);
-                            const unsigned off = (hi >> 16) + ((x <= __uint_as_float((unsigned)v[u])) ? 0u : 8u);
-                            v[u] = *(const unsigned long long *)(tb[u] + off);
-                            any = true;
+                        for (int u = 0; u < kEvalPer; u++) {
+                            const unsigned hi = (unsigned)(v[u] >> 32), co = hi & 0xffffu;
+                            if (co != 0xffffu) {                               // Split.eval: value <= threshold goes left (Split.java:118)
+                                const float x = *(const float *)(sXb + co);
+                                const unsigned off = (hi >> 16) + ((x <= __uint_as_float((unsigned)v[u])) ? 0u : 8u);
+                                v[u] = *(const unsigned long long *)(tb[u] + off);
+                                any = true;
+                            }
                         }
                     }
-                }
 #pragma unroll
-                for (int u = 0; u < kEvalIlp; u++) if (g + u < tt) sO[(g + u) * kEvalDocs + doc] = __uint_as_float((unsigned)v[u]);
+                    for (int u = 0; u < kEvalPer; u++) if (u < cnt) so[u * kEvalDocs] = __uint_as_float((unsigned)v[u]);
+                }
+            } else if (k > 0 && doc < nd) {                                    // accumulate the previous tile while this one is walked
+                const float *po = sO + (size_t)(cb ^ 1) * kEvalTreeTile * kEvalDocs + doc, *pw = sW + (cb ^ 1) * kEvalTreeTile;
+                for (int t = 0; t < tt_prev; t++) s = (float)((double)s + (double)po[t * kEvalDocs] * (double)pw[t]);   // Ensemble.java:113
             }
-            __syncthreads();
-            if (part == 0 && doc < nd)
-                for (int t = 0; t < tt; t++) s = (float)((double)s + (double)sO[t * kEvalDocs + doc] * (double)sW[t]);   // Ensemble.java:113
+            tt_prev = tt;
         }
-        if (part == 0 && doc < nd) out[d0 + doc] = s;
+        __syncthreads();
+        if (!walker && doc < nd) {
+            if (k > 0) {
+                const int cb = (k - 1) & 1;
+                const float *po = sO + (size_t)cb * kEvalTreeTile * kEvalDocs + doc, *pw = sW + cb * kEvalTreeTile;
+                for (int t = 0; t < tt_prev; t++) s = (float)((double)s + (double)po[t * kEvalDocs] * (double)pw[t]);
+            }
+            out[d0 + doc] = s;
+        }
     }
 }
 }  // namespace rl
@@ -1613,7 +1631,7 @@ static int model_eval_launch(rl_model *m, const float *dX, int64_t n_docs, int32
     static const bool force_generic = getenv("RLHIP_EVAL_GENERIC") != nullptr;       // cross-checks in the tests
     if (m->d_pack && lds <= (size_t)160 * 1024 && !force_generic) {
         const int64_t tiles = (n_docs + kEvalDocs - 1) / kEvalDocs;
-        hipLaunchKernelGGL(k_model_eval_tiled, dim3((unsigned)std::min<int64_t>(tiles, 256 * 256)), dim3(kEvalDocs * kEvalParts), lds, s,
+        hipLaunchKernelGGL(k_model_eval_tiled, dim3((unsigned)std::min<int64_t>(tiles, 256 * 256)), dim3(kEvalThreads), lds, s,
                            (const unsigned long long *)m->d_pack, (const float *)m->d_w, m->maxn, (int)m->trees.size(), dX, n_docs, row_stride, cols, dO);
     } else {
         hipLaunchKernelGGL(k_model_eval, dim3((unsigned)std::min<int64_t>(8192, (n_docs + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, m->ens,
