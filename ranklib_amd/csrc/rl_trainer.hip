@@ -262,11 +262,12 @@ static int alloc_chain(rl_trainer *t, ChainBufs &b, int maxseg, int A, int64_t n
     RL_HIP(hipMemset(b.st_status, 0, (size_t)A * maxseg * sizeof(int32_t)));
     RL_HIP(hipMemset(b.miss, 0, (size_t)A * maxseg * sizeof(int32_t)));
     RL_HIP(t->pool.alloc(&b.arrive, (size_t)1)); RL_HIP(hipMemset(b.arrive, 0, sizeof(unsigned long long)));
-    if (hint) {
-        RL_HIP(hipHostMalloc((void **)&b.h_progress, sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
-        *b.h_progress = 0;
-        RL_HIP(hipHostGetDevicePointer((void **)&b.progress, b.h_progress, 0));
-        t->pinned.push_back(b.h_progress);
+    if (hint) {      // optional, like the trainer's progress word
+        if (hipHostMalloc((void **)&b.h_progress, sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+            *b.h_progress = 0;
+            t->pinned.push_back(b.h_progress);
+            if (hipHostGetDevicePointer((void **)&b.progress, b.h_progress, 0) != hipSuccess) { b.progress = nullptr; b.h_progress = nullptr; (void)hipGetLastError(); }
+        } else { b.h_progress = nullptr; (void)hipGetLastError(); }
     }
     RL_HIP(t->pool.alloc(&b.stats, (size_t)4));
     RL_HIP(hipMemset(b.stats, 0, 4 * sizeof(int32_t)));
@@ -909,10 +910,17 @@ int rl_init(rl_trainer *t)
     RL_HIP(hipMemset(c.st, 0, sizeof(TreeState)));
     t->tree_seq = 0;
     if (const char *e = getenv("RLHIP_STEP_AHEAD")) t->step_ahead = std::max(0, atoi(e));     // tuning knob
-    if (!t->h_progress) RL_HIP(hipHostMalloc((void **)&t->h_progress, sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
-    *t->h_progress = 0;
+    // the progress word is an optimisation: without host-visible coherent memory the host simply enqueues every step
     c.progress = nullptr;
-    if (t->step_ahead > 0 && !t->dist) RL_HIP(hipHostGetDevicePointer((void **)&c.progress, t->h_progress, 0));
+    if (!t->h_progress && hipHostMalloc((void **)&t->h_progress, sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+        t->h_progress = nullptr; (void)hipGetLastError();
+    }
+    if (t->h_progress) {
+        *t->h_progress = 0;
+        if (t->step_ahead > 0 && !t->dist && hipHostGetDevicePointer((void **)&c.progress, t->h_progress, 0) != hipSuccess) {
+            c.progress = nullptr; (void)hipGetLastError();
+        }
+    }
     RL_HIP(hipMemset(c.nodes, 0, ((size_t)c.NC + 2) * sizeof(NodeRec)));
     RL_HIP(t->pool.alloc(&c.queue, (size_t)c.MAXN + 2));
     RL_HIP(t->pool.alloc(&c.part_sum, (size_t)c.maxChunks * F * TS)); RL_HIP(t->pool.alloc(&c.part_cnt, (size_t)c.maxChunks * F * TS));
