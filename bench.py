@@ -123,9 +123,14 @@ def bench_infer(args):
     if args.cpu_rounds > 0:
         import oracle_ffi as O
         threads = args.cpu_threads or (os.cpu_count() or 1)
-        ns = min(n, max(threads * 64, int(2.0e9 / (nt * max(visits, 1.0)) / 4)))      # ~ a few seconds of CPU work
-        rows = dX[:ns].cpu().numpy()
         all_trees = [trees[i % len(trees)] for i in range(nt)]
+        # a short probe sizes the timed sample to ~3 s of wall time on all host threads (thread start-up dominates shorter runs)
+        probe = min(n, threads * 64)
+        tc = time.perf_counter()
+        O.eval_flat_model(all_trees, dX[:probe].cpu().numpy(), n_threads=threads)
+        t_probe = max(time.perf_counter() - tc, 1e-3)
+        ns = int(min(n, max(probe, probe * 3.0 / t_probe)))
+        rows = dX[:ns].cpu().numpy()
         tc = time.perf_counter()
         ref = O.eval_flat_model(all_trees, rows, n_threads=threads)
         t_cpu = time.perf_counter() - tc
