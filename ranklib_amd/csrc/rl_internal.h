@@ -39,7 +39,6 @@ constexpr int kSpec = RL_KSPEC;      // nodes split (speculatively, in queue ord
 constexpr int kLambdaWaveCap = 384;  // docs/query handled by the wave-per-query lambda kernel
 constexpr int kLambdaBlockCap = 5000;
 constexpr int kLambdaFusedMaxK = 16;  // NDCG@k up to this k uses the LDS-resident fused lambda kernel
-constexpr int kLambdaFusedSmall = 128;// queries up to this length use the 128-thread variant// docs/query handled by the block-per-query kernel
 
 // A tree node while the tree is being grown (device resident).
 // Mirrors Split + its FeatureHistogram scalars (learning/tree/Split.java:22-38,

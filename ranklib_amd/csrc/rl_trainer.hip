@@ -53,7 +53,9 @@ struct DataSet {
     double *d_ss = nullptr; float *d_sl = nullptr; int32_t *d_srel = nullptr, *d_sidx = nullptr, *d_docq = nullptr;   // ranked order (training set only)
     int32_t *d_aux_i = nullptr; double *d_aux_a = nullptr, *d_aux_b = nullptr;   // swapChange tables of MAP / ERR in ranked order
     int32_t *d_qsmall = nullptr, *d_qbig = nullptr; int32_t n_small = 0, n_big = 0; bool all_small = false;
-    int32_t *d_q128 = nullptr, *d_qlong = nullptr; int32_t n_q128 = 0, n_qlong = 0;   // split at kLambdaFusedSmall
+    // queries by length class for the fused lambda kernel: <= 64, <= 128, <= 192 documents, longer (tiled by 256); a block is as
+    // wide as its class, so short lists do not leave most of a block idle
+    int32_t *d_qcls[4] = {nullptr, nullptr, nullptr, nullptr}; int32_t n_qcls[4] = {0, 0, 0, 0};
     int32_t maxq = 0;
 };
 
@@ -182,14 +184,17 @@ static int upload_query_side(rl_trainer *t, DataSet &d, const std::vector<double
     RL_HIP(t->pool.alloc(&d.d_qbig, big.size()));
     if (!small.empty()) RL_HIP(hipMemcpy(d.d_qsmall, small.data(), small.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (!big.empty()) RL_HIP(hipMemcpy(d.d_qbig, big.data(), big.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    std::vector<int32_t> q128, qlong;
-    for (int32_t q = 0; q < d.Q; q++) ((d.qoff[q + 1] - d.qoff[q]) <= kLambdaFusedSmall ? q128 : qlong).push_back(q);
-    std::stable_sort(q128.begin(), q128.end(), by_len);
-    std::stable_sort(qlong.begin(), qlong.end(), by_len);
-    d.n_q128 = (int32_t)q128.size(); d.n_qlong = (int32_t)qlong.size();
-    RL_HIP(t->pool.alloc(&d.d_q128, q128.size())); RL_HIP(t->pool.alloc(&d.d_qlong, qlong.size()));
-    if (!q128.empty()) RL_HIP(hipMemcpy(d.d_q128, q128.data(), q128.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    if (!qlong.empty()) RL_HIP(hipMemcpy(d.d_qlong, qlong.data(), qlong.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    std::vector<int32_t> qcls[4];
+    for (int32_t q = 0; q < d.Q; q++) {
+        const int n = d.qoff[q + 1] - d.qoff[q];
+        qcls[n <= 64 ? 0 : n <= 128 ? 1 : n <= 192 ? 2 : 3].push_back(q);
+    }
+    for (int cI = 0; cI < 4; cI++) {
+        std::stable_sort(qcls[cI].begin(), qcls[cI].end(), by_len);
+        d.n_qcls[cI] = (int32_t)qcls[cI].size();
+        RL_HIP(t->pool.alloc(&d.d_qcls[cI], qcls[cI].size()));
+        if (!qcls[cI].empty()) RL_HIP(hipMemcpy(d.d_qcls[cI], qcls[cI].data(), qcls[cI].size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     return RL_OK;
 }
 
@@ -394,12 +399,17 @@ static int enqueue_round(rl_trainer *t)
                   t->d_T, c.lw, &c.st->maxabs_bits, c.N, c.k, c.k, c.metric, t->p.metric_k,
                   t->tr.d_aux_i, t->tr.d_aux_a, t->tr.d_aux_b, t->d_wmax};
         if (t->d_T == nullptr) {
-            const size_t l128 = (size_t)c.k * (128 + 8) * 16 + (size_t)c.k * 24;
-            const size_t l256 = (size_t)c.k * (256 + 8) * 16 + (size_t)c.k * 24;
-            if (t->tr.n_q128 > 0) hipLaunchKernelGGL(k_lambda_fused<128>, dim3(t->tr.n_q128), dim3(128), l128, s, g, (const int *)t->tr.d_q128, t->tr.n_q128);
-            g.blockmax = t->d_wmax + t->tr.n_q128;
-            if (t->tr.n_qlong > 0) hipLaunchKernelGGL(k_lambda_fused<256>, dim3(t->tr.n_qlong), dim3(256), l256, s, g, (const int *)t->tr.d_qlong, t->tr.n_qlong);
-            n_max = t->tr.n_q128 + t->tr.n_qlong;
+            auto lds_of = [&](int bt) { return (size_t)c.k * (bt + 8) * 16 + (size_t)c.k * 24; };
+            n_max = 0;
+            const DataSet &d = t->tr;
+            if (d.n_qcls[0] > 0) hipLaunchKernelGGL(k_lambda_fused<64>, dim3(d.n_qcls[0]), dim3(64), lds_of(64), s, g, (const int *)d.d_qcls[0], d.n_qcls[0]);
+            n_max += d.n_qcls[0]; g.blockmax = t->d_wmax + n_max;
+            if (d.n_qcls[1] > 0) hipLaunchKernelGGL(k_lambda_fused<128>, dim3(d.n_qcls[1]), dim3(128), lds_of(128), s, g, (const int *)d.d_qcls[1], d.n_qcls[1]);
+            n_max += d.n_qcls[1]; g.blockmax = t->d_wmax + n_max;
+            if (d.n_qcls[2] > 0) hipLaunchKernelGGL(k_lambda_fused<192>, dim3(d.n_qcls[2]), dim3(192), lds_of(192), s, g, (const int *)d.d_qcls[2], d.n_qcls[2]);
+            n_max += d.n_qcls[2]; g.blockmax = t->d_wmax + n_max;
+            if (d.n_qcls[3] > 0) hipLaunchKernelGGL(k_lambda_fused<256>, dim3(d.n_qcls[3]), dim3(256), lds_of(256), s, g, (const int *)d.d_qcls[3], d.n_qcls[3]);
+            n_max += d.n_qcls[3];
         } else {
             const unsigned nb = (unsigned)((c.N + kThreads - 1) / kThreads);
             hipLaunchKernelGGL(k_pair_terms, dim3(nb), dim3(kThreads), 0, s, g);
@@ -683,7 +693,7 @@ int rl_create(const rl_params *p, rl_trainer **out)
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     RL_HIP(hipFuncSetAttribute((const void *)k_rank_block, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaBlockCap * 12));
-    RL_HIP(hipFuncSetAttribute((const void *)k_lambda_fused<256>, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaFusedMaxK * 256 * 16 + 2048));
+    RL_HIP(hipFuncSetAttribute((const void *)k_lambda_fused<256>, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaFusedMaxK * (256 + 8) * 16 + 2048));
     RL_HIP(hipFuncSetAttribute((const void *)k_chain_stitch, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     *out = t.release();
     return RL_OK;
