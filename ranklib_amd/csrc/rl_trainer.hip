@@ -55,7 +55,7 @@ struct DataSet {
     int32_t *d_qsmall = nullptr, *d_qbig = nullptr; int32_t n_small = 0, n_big = 0; bool all_small = false;
     // queries by length class for the fused lambda kernel: <= 64, <= 128, <= 192 documents, longer (tiled by 256); a block is as
     // wide as its class, so short lists do not leave most of a block idle
-    int32_t *d_qcls[4] = {nullptr, nullptr, nullptr, nullptr}; int32_t n_qcls[4] = {0, 0, 0, 0};
+    int32_t *d_qcls[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; int32_t n_qcls[5] = {0, 0, 0, 0, 0};     // [4]: <= 16 documents (k_lambda_tiny)
     int32_t maxq = 0;
 };
 
@@ -184,12 +184,18 @@ static int upload_query_side(rl_trainer *t, DataSet &d, const std::vector<double
     RL_HIP(t->pool.alloc(&d.d_qbig, big.size()));
     if (!small.empty()) RL_HIP(hipMemcpy(d.d_qsmall, small.data(), small.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (!big.empty()) RL_HIP(hipMemcpy(d.d_qbig, big.data(), big.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    std::vector<int32_t> qcls[4];
+    std::vector<int32_t> qcls[5];
     for (int32_t q = 0; q < d.Q; q++) {
         const int n = d.qoff[q + 1] - d.qoff[q];
-        qcls[n <= 64 ? 0 : n <= 128 ? 1 : n <= 192 ? 2 : 3].push_back(q);
+        qcls[n <= kLambdaTinyDocs ? 4 : n <= 64 ? 0 : n <= 128 ? 1 : n <= 192 ? 2 : 3].push_back(q);
     }
-    for (int cI = 0; cI < 4; cI++) {
+    size_t tiny_min = 4096;
+    if (const char *e = getenv("RLHIP_TINY_MIN")) tiny_min = (size_t)std::max(0, atoi(e));      // tests / tuning
+    if (qcls[4].size() < tiny_min) {   // a handful of tiny lists is not worth a launch of its own: they join the 64-wide class
+        qcls[0].insert(qcls[0].end(), qcls[4].begin(), qcls[4].end());
+        qcls[4].clear();
+    }
+    for (int cI = 0; cI < 5; cI++) {
         std::stable_sort(qcls[cI].begin(), qcls[cI].end(), by_len);
         d.n_qcls[cI] = (int32_t)qcls[cI].size();
         RL_HIP(t->pool.alloc(&d.d_qcls[cI], qcls[cI].size()));
@@ -402,6 +408,12 @@ static int enqueue_round(rl_trainer *t)
             auto lds_of = [&](int bt) { return (size_t)c.k * (bt + 8) * 16 + (size_t)c.k * 24; };
             n_max = 0;
             const DataSet &d = t->tr;
+            if (d.n_qcls[4] > 0) {
+                const int nb = (d.n_qcls[4] + kLambdaTinyGroups - 1) / kLambdaTinyGroups;
+                hipLaunchKernelGGL(k_lambda_tiny, dim3(nb), dim3(kLambdaTinyDocs * kLambdaTinyGroups),
+                                   (size_t)kLambdaTinyGroups * lambda_tiny_group_bytes(c.k), s, g, (const int *)d.d_qcls[4], d.n_qcls[4]);
+                n_max += nb; g.blockmax = t->d_wmax + n_max;
+            }
             if (d.n_qcls[0] > 0) hipLaunchKernelGGL(k_lambda_fused<64>, dim3(d.n_qcls[0]), dim3(64), lds_of(64), s, g, (const int *)d.d_qcls[0], d.n_qcls[0]);
             n_max += d.n_qcls[0]; g.blockmax = t->d_wmax + n_max;
             if (d.n_qcls[1] > 0) hipLaunchKernelGGL(k_lambda_fused<128>, dim3(d.n_qcls[1]), dim3(128), lds_of(128), s, g, (const int *)d.d_qcls[1], d.n_qcls[1]);
@@ -693,6 +705,7 @@ int rl_create(const rl_params *p, rl_trainer **out)
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     RL_HIP(hipFuncSetAttribute((const void *)k_rank_block, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaBlockCap * 12));
+    RL_HIP(hipFuncSetAttribute((const void *)k_lambda_tiny, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaTinyGroups * lambda_tiny_group_bytes(kLambdaFusedMaxK)));
     RL_HIP(hipFuncSetAttribute((const void *)k_lambda_fused<256>, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaFusedMaxK * (256 + 8) * 16 + 2048));
     RL_HIP(hipFuncSetAttribute((const void *)k_chain_stitch, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     *out = t.release();

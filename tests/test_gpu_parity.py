@@ -356,6 +356,36 @@ def test_other_rankers_and_metrics_match_the_oracle(ranker, metric, k, kind, see
     assert text.startswith("## %s\n" % ("MART" if ranker == "MART" else "LambdaMART"))
 
 
+def test_lambda_kernel_variants_by_list_length_give_identical_lambdas(monkeypatch):
+    """k_lambda_tiny (<= 16 documents, 16-lane groups) and the 64 / 128 / 192 / 256-wide block variants against the oracle, and
+    against each other on the same mixed-length data (RLHIP_TINY_MIN moves the tiny lists between the two kernels)."""
+    rng = np.random.default_rng(4)
+    sizes = np.concatenate([rng.integers(1, 17, 300), rng.integers(17, 65, 60), rng.integers(65, 129, 30), rng.integers(129, 193, 15),
+                            rng.integers(193, 300, 8), [16, 17, 64, 65, 128, 129, 192, 193, 256, 257]])
+    rng.shuffle(sizes)
+    qoff = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    n = int(qoff[-1])
+    X = rng.random((n, 6)).astype(np.float32)
+    lab = np.floor(3 * X[:, 0] * X[:, 1] + 2 * rng.random(n)).astype(np.float32)
+    res = []
+    for tiny_min in ("1", "1000000"):
+        monkeypatch.setenv("RLHIP_TINY_MIN", tiny_min)
+        g = N.Trainer(n_trees=3, n_leaves=6)
+        g.set_train(X, lab, qoff)
+        g.init()
+        rec = []
+        for _ in range(3):
+            g.boost_round()
+            rec.append((g.array("LAMBDA").copy(), g.array("WEIGHT").copy()))
+        res.append(rec)
+    o = O.Oracle(X, lab, qoff, n_trees=3, n_leaves=6)
+    o.init()
+    for r in range(3):
+        o.round()
+        for rec in res:
+            assert np.array_equal(rec[r][0], o.lambdas()) and np.array_equal(rec[r][1], o.weights()), "round %d" % r
+
+
 # ---- SURVEY.md 8f-4: feature sampling of Random Forests (FeatureHistogram.samplingRate), seeded ------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("ranker,frate,n_feat,leaves,seed", [
