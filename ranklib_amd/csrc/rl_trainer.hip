@@ -52,7 +52,7 @@ struct DataSet {
     double *d_scores = nullptr, *d_ndcg = nullptr;
     double *d_ss = nullptr; float *d_sl = nullptr; int32_t *d_srel = nullptr, *d_sidx = nullptr, *d_docq = nullptr;   // ranked order (training set only)
     int32_t *d_aux_i = nullptr; double *d_aux_a = nullptr, *d_aux_b = nullptr;   // swapChange tables of MAP / ERR in ranked order
-    int32_t *d_qsmall = nullptr, *d_qbig = nullptr; int32_t n_small = 0, n_big = 0; bool all_small = false;
+    int32_t *d_qsmall = nullptr, *d_qbig = nullptr, *d_qtiny = nullptr; int32_t n_small = 0, n_big = 0, n_tiny = 0; bool all_small = false;
     // queries by length class for the fused lambda kernel: <= 64, <= 128, <= 192 documents, longer (tiled by 256); a block is as
     // wide as its class, so short lists do not leave most of a block idle
     int32_t *d_qcls[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; int32_t n_qcls[5] = {0, 0, 0, 0, 0};     // [4]: <= 16 documents (k_lambda_tiny)
@@ -172,8 +172,17 @@ static int upload_query_side(rl_trainer *t, DataSet &d, const std::vector<double
     RL_HIP(t->pool.alloc(&d.d_scores, (size_t)d.N));
     RL_HIP(hipMemset(d.d_scores, 0, d.N * sizeof(double)));                // modelScores = 0  LambdaMART.java:86
     RL_HIP(t->pool.alloc(&d.d_ndcg, (size_t)d.Q));
-    std::vector<int32_t> small, big;
-    for (int32_t q = 0; q < d.Q; q++) ((d.qoff[q + 1] - d.qoff[q]) <= kLambdaWaveCap ? small : big).push_back(q);
+    size_t tiny_min = 4096;           // lists of <= 16 documents get kernels of their own when there are enough of them
+    if (const char *e = getenv("RLHIP_TINY_MIN")) tiny_min = (size_t)std::max(0, atoi(e));      // tests / tuning
+    std::vector<int32_t> small, big, tiny;
+    for (int32_t q = 0; q < d.Q; q++) {
+        const int n = d.qoff[q + 1] - d.qoff[q];
+        (n <= kRankTinyDocs ? tiny : n <= kLambdaWaveCap ? small : big).push_back(q);
+    }
+    if (tiny.size() < tiny_min) { small.insert(small.end(), tiny.begin(), tiny.end()); tiny.clear(); }
+    d.n_tiny = (int32_t)tiny.size();
+    RL_HIP(t->pool.alloc(&d.d_qtiny, tiny.size()));
+    if (!tiny.empty()) RL_HIP(hipMemcpy(d.d_qtiny, tiny.data(), tiny.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     // longest first: a block's work grows with n (n^2 for the rank), so late long lists would leave a tail
     auto by_len = [&](int32_t a, int32_t b) { return (d.qoff[a + 1] - d.qoff[a]) > (d.qoff[b + 1] - d.qoff[b]); };
     std::stable_sort(small.begin(), small.end(), by_len);
@@ -189,8 +198,6 @@ static int upload_query_side(rl_trainer *t, DataSet &d, const std::vector<double
         const int n = d.qoff[q + 1] - d.qoff[q];
         qcls[n <= kLambdaTinyDocs ? 4 : n <= 64 ? 0 : n <= 128 ? 1 : n <= 192 ? 2 : 3].push_back(q);
     }
-    size_t tiny_min = 4096;
-    if (const char *e = getenv("RLHIP_TINY_MIN")) tiny_min = (size_t)std::max(0, atoi(e));      // tests / tuning
     if (qcls[4].size() < tiny_min) {   // a handful of tiny lists is not worth a launch of its own: they join the 64-wide class
         qcls[0].insert(qcls[0].end(), qcls[4].begin(), qcls[4].end());
         qcls[4].clear();
@@ -350,6 +357,9 @@ static int launch_rank(rl_trainer *t, DataSet &d, const double *scores, double *
     RankArgs a{scores, d.d_labels, d.d_qoff, d.d_ideal1, t->ctx.disc,
                ranked ? d.d_ss : nullptr, ranked ? d.d_sl : nullptr, ranked ? d.d_srel : nullptr, ranked ? d.d_sidx : nullptr,
                out, t->p.metric_k, t->p.metric, ranked ? d.d_aux_i : nullptr, ranked ? d.d_aux_a : nullptr, ranked ? d.d_aux_b : nullptr};
+    if (d.n_tiny > 0)
+        hipLaunchKernelGGL(k_rank_tiny, dim3((d.n_tiny + kRankTinyGroups - 1) / kRankTinyGroups), dim3(kRankTinyDocs * kRankTinyGroups), 0, t->stream, a,
+                           (const int *)d.d_qtiny, d.n_tiny);
     if (d.n_small > 0)
         hipLaunchKernelGGL(k_rank_wave, dim3((d.n_small + 3) / 4), dim3(kThreads), 4 * kLambdaWaveCap * 12, t->stream, a,
                            d.all_small ? (const int *)nullptr : d.d_qsmall, d.n_small);
