@@ -460,7 +460,7 @@ static int enqueue_round(rl_trainer *t)
         int rcd = t->dist->allreduce(c.dist_buf, (size_t)c.F * c.TS * 3 + 4, DT_I64, OP_SUM, s);
         if (rcd) return rcd;
         hipLaunchKernelGGL((k_hist_finish<true, true>), dim3(c.F), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
-    } else hipLaunchKernelGGL((k_hist_finish<true, false>), dim3(c.F), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
+    } else hipLaunchKernelGGL((k_hist_finish<true, false>), dim3(c.n_live), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
     // Growth steps: each prepares up to kSpec queue nodes and commits as many splits as the fit loop allows; L-1 steps
     // always suffice (every step commits at least the head of the queue); finished trees make the rest no-ops.
     const int steps = std::max(c.L - 1, 1);
@@ -505,7 +505,7 @@ static int enqueue_round(rl_trainer *t)
                 RL_HIP(hipMemcpy(&done, &c.st->done, sizeof(done), hipMemcpyDeviceToHost));
                 if (done) break;
             }
-        } else hipLaunchKernelGGL((k_hist_finish<false, false>), dim3(c.F, kSpec), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
+        } else hipLaunchKernelGGL((k_hist_finish<false, false>), dim3(c.n_live, kSpec), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
     }
     hipLaunchKernelGGL(k_leaf_table, dim3(1), dim3(kThreads), 0, s, c, t->leaf_chain, t->d_seg_buf);
     if (t->p.flags & RL_FLAG_SERIAL_CHAIN) {
@@ -862,6 +862,16 @@ int rl_init(rl_trainer *t)
     RL_HIP(hipMemsetAsync(d_thr, 0, (size_t)F * TS * sizeof(float), s));
     RL_HIP(hipMemcpy2DAsync(d_thr, TS * sizeof(float), thr0, TS0 * sizeof(float), TS * sizeof(float), F, hipMemcpyDeviceToDevice, s));
     c.thr = d_thr; c.nthr = d_nthr;
+    c.live = nullptr; c.n_live = F;
+    if (!t->dist) {       // features that can split at all (> 1 distinct value <=> more than the value + Float.MAX_VALUE thresholds)
+        std::vector<int32_t> live;
+        for (int f = 0; f < F; f++) if (h_nthr[f] > 2) live.push_back(f);
+        if (live.empty()) live.push_back(0);
+        int32_t *d_live = nullptr;
+        RL_HIP(t->pool.alloc(&d_live, live.size()));
+        RL_HIP(hipMemcpy(d_live, live.data(), live.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        c.live = d_live; c.n_live = (int32_t)live.size();
+    }
     if ((size_t)TS * 12 > (size_t)kHistLdsBytes) return fail(RL_ERR_UNSUPPORTED, "too many threshold candidates for the LDS histogram");
     // features of a 16-feature group handled by one histogram block: all 16 when the LDS budget allows
     c.FG = kHistFG;
@@ -958,7 +968,14 @@ int rl_init(rl_trainer *t)
     RL_HIP(t->pool.alloc(&c.queue, (size_t)c.MAXN + 2));
     RL_HIP(t->pool.alloc(&c.part_sum, (size_t)c.maxChunks * F * TS)); RL_HIP(t->pool.alloc(&c.part_cnt, (size_t)c.maxChunks * F * TS));
     RL_HIP(t->pool.alloc(&c.part_tot, (size_t)std::max(c.maxChunks, (N + kMinChunk - 1) / kMinChunk) + 1));
-    RL_HIP(t->pool.alloc(&c.fb, (size_t)kSpec * 2 * F)); RL_HIP(t->pool.alloc(&c.fb_root, (size_t)2 + kSpec)); c.fb_sq = c.fb_root + 2;
+    RL_HIP(t->pool.alloc(&c.fb, (size_t)kSpec * 2 * F));
+    {   // records of features that never get a finish block: "no admissible split"
+        std::vector<FeatBest> init((size_t)kSpec * 2 * F);
+        const double m1 = -1.0;
+        for (auto &r : init) { memcpy(&r.S, &m1, 8); r.hi = 0; r.lo = 0; r.tc = 0; }
+        RL_HIP(hipMemcpy(c.fb, init.data(), init.size() * sizeof(FeatBest), hipMemcpyHostToDevice));
+    }
+    RL_HIP(t->pool.alloc(&c.fb_root, (size_t)2 + kSpec)); c.fb_sq = c.fb_root + 2;
     RL_HIP(t->pool.alloc(&c.tile_cnt, (size_t)c.nTiles)); RL_HIP(t->pool.alloc(&c.tile_sq, (size_t)c.nTiles));
     RL_HIP(t->pool.alloc(&c.tile_desc, (size_t)c.nTiles)); RL_HIP(hipMemset(c.tile_desc, 0, (size_t)c.nTiles * 8));
     RL_HIP(t->pool.alloc(&c.grow_stats, (size_t)4)); RL_HIP(hipMemset(c.grow_stats, 0, 16));
