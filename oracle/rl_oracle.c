@@ -667,7 +667,7 @@ ro_trainer *ro_create(const ro_params *p, const float *X, int64_t n_docs, int32_
     for (int32_t f = 0; f < n_features; f++) t->feature_ids[f] = feature_ids ? feature_ids[f] : f + 1;
     dataset_set(&t->tr, X, n_docs, n_features, labels, qoff, n_queries, qkey, 0);
     /* column-major copy so that later stages never touch the caller's X */
-    t->Xcol = (float *)malloc(sizeof(float) * (size_t)(n_docs * n_features ? n_docs * n_features : 1));
+    t->Xcol = (float *)malloc(sizeof(float) * (size_t)((n_docs > 0 && n_features > 0) ? n_docs * n_features : 1));
     for (int64_t k = 0; k < n_docs; k++)
         for (int32_t f = 0; f < n_features; f++) t->Xcol[(int64_t)f * n_docs + k] = X[k * n_features + f];
     t->tr.X = NULL;
