@@ -650,7 +650,7 @@ static void dataset_set(dataset_t *d, const float *X, int64_t n, int32_t F, cons
     }
     d->Xown = NULL;
     if (copyX) {
-        d->Xown = (float *)malloc(sizeof(float) * (size_t)(n * F ? n * F : 1));
+        d->Xown = (float *)malloc(sizeof(float) * (size_t)((n > 0 && F > 0) ? n * F : 1));
         memcpy(d->Xown, X, sizeof(float) * (size_t)(n * F));
         d->X = d->Xown;
     }
