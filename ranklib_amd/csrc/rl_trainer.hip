@@ -372,7 +372,7 @@ static int launch_rank(rl_trainer *t, DataSet &d, const double *scores, double *
 template <bool ROOT>
 static void launch_hist(const Ctx &c, int gx, int gy, size_t lds, hipStream_t s)
 {
-    const dim3 g(gx, gy), b(kThreads);
+    const dim3 g(gx, (gy + 7) & ~7), b(kThreads);      // the XCD-aware block map of k_hist wants a multiple of 8 chunks (the extra blocks exit)
     if (c.sub == 16 && c.TS <= kHistLdsStride) { hipLaunchKernelGGL((k_hist<ROOT, 16, kHistLdsStride>), g, b, lds, s, c); return; }
     switch (c.sub) {
     case 16: hipLaunchKernelGGL((k_hist<ROOT, 16, 0>), g, b, lds, s, c); break;
