@@ -493,7 +493,10 @@ static int enqueue_round(rl_trainer *t)
         }
         if (t->dist) {
             hipLaunchKernelGGL(k_hist_reduce, dim3(c.F, kSpec), dim3(kFinThreads), red_lds, s, c, 0);
-            int rcd = t->dist->allreduce(c.dist_buf, slot_words * kSpec, DT_I64, OP_SUM, s);
+            // growth step `it` works on at most min(kSpec, 2^it) nodes (1 after the root, then at most twice the commits of the step
+            // before): the first steps -- the ones with the largest histograms to wait for -- reduce one or two slots, not kSpec
+            const int max_slots = std::min(kSpec, 1 << std::min(it, 8));
+            int rcd = t->dist->allreduce(c.dist_buf, slot_words * max_slots, DT_I64, OP_SUM, s);
             if (rcd) return rcd;
             hipLaunchKernelGGL((k_hist_finish<false, true>), dim3(c.F, kSpec), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
             // Sharded runs pay a collective per step even when the tree is already finished, so the host looks at the
