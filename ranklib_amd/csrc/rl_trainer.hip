@@ -474,14 +474,29 @@ static int enqueue_round(rl_trainer *t)
             const unsigned long long want = ((unsigned long long)t->tree_seq << 32) | ((unsigned long long)(unsigned)(it - t->step_ahead) << 1);
             const auto finished = [&](unsigned long long w) { return (w >> 32) == t->tree_seq && (w & 1); };
             unsigned long long w = __atomic_load_n(t->h_progress, __ATOMIC_ACQUIRE);
-            if (w < want && !finished(w)) {
+            if (t->dist) {
+                // Deterministic over the ranks (they grow the same tree): wait -- without a timeout -- until growth step
+                // it - step_ahead has been selected or the tree is finished, and stop only if the tree was finished by a step
+                // <= it - step_ahead.  The word keeps (step at which `done` was set, done) once the tree is finished, so a rank
+                // that looks early and one that looks late take the same decision at the same `it`.
+                unsigned spins = 0;
+                while (w < want && !finished(w)) {
+                    w = __atomic_load_n(t->h_progress, __ATOMIC_ACQUIRE);
+                    if ((++spins & 0xfffff) == 0) {
+                        const hipError_t q = hipStreamQuery(s);
+                        if (q != hipSuccess && q != hipErrorNotReady) return fail(RL_ERR_HIP, std::string("device error while growing a tree: ") + hipGetErrorString(q));
+                    }
+                }
+                const int step_w = (int)((unsigned)(w & 0xffffffffull) >> 1);
+                if (finished(w) && step_w <= it - t->step_ahead) break;
+            } else if (w < want && !finished(w)) {
                 const auto t0 = std::chrono::steady_clock::now();
                 unsigned spins = 0;
                 while ((w = __atomic_load_n(t->h_progress, __ATOMIC_ACQUIRE)) < want && !finished(w)) {
                     if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) { throttle = false; break; }
                 }
             }
-            if (finished(w)) break;
+            if (!t->dist && finished(w)) break;
         }
         if (t->dist) {      // local child sizes are unknown in advance: count pass, then scatter
             hipLaunchKernelGGL(k_part_count, dim3(c.nTiles), dim3(kThreads), 0, s, c);
@@ -502,7 +517,7 @@ static int enqueue_round(rl_trainer *t)
             // Sharded runs pay a collective per step even when the tree is already finished, so the host looks at the
             // (rank-invariant) `done` flag now and then and stops enqueuing: a stream sync costs far less than the
             // all-reduces of ~20 empty steps.  One GPU keeps the fully asynchronous schedule (an empty step is 3 tiny launches).
-            if (it + 1 < steps && it >= 7 && (it - 7) % 3 == 0) {
+            if (!c.progress && it + 1 < steps && it >= 7 && (it - 7) % 3 == 0) {
                 int32_t done = 0;
                 RL_HIP(hipStreamSynchronize(s));
                 RL_HIP(hipMemcpy(&done, &c.st->done, sizeof(done), hipMemcpyDeviceToHost));
@@ -963,9 +978,22 @@ int rl_init(rl_trainer *t)
     }
     if (t->h_progress) {
         *t->h_progress = 0;
-        if (t->step_ahead > 0 && !t->dist && hipHostGetDevicePointer((void **)&c.progress, t->h_progress, 0) != hipSuccess) {
+        if (t->step_ahead > 0 && hipHostGetDevicePointer((void **)&c.progress, t->h_progress, 0) != hipSuccess) {
             c.progress = nullptr; (void)hipGetLastError();
         }
+    }
+    if (t->dist) {
+        // Sharded runs: every rank must enqueue the same collectives, so the way a tree's end is detected has to be the same on
+        // all of them: the progress word (deterministic rule in enqueue_round) only if every rank has one, else the stream
+        // synchronisation at fixed steps.
+        int32_t have = (c.progress != nullptr && !getenv("RLHIP_DIST_SYNC_STOP")) ? 1 : 0, *d_have = nullptr;
+        RL_HIP(t->pool.alloc(&d_have, (size_t)1));
+        RL_HIP(hipMemcpy(d_have, &have, sizeof(have), hipMemcpyHostToDevice));
+        int rcd = t->dist->allreduce(d_have, 1, DT_I32, OP_MIN, t->stream);
+        if (rcd) return rcd;
+        RL_HIP(hipStreamSynchronize(t->stream));
+        RL_HIP(hipMemcpy(&have, d_have, sizeof(have), hipMemcpyDeviceToHost));
+        if (!have) c.progress = nullptr;
     }
     RL_HIP(hipMemset(c.nodes, 0, ((size_t)c.NC + 2) * sizeof(NodeRec)));
     RL_HIP(t->pool.alloc(&c.queue, (size_t)c.MAXN + 2));

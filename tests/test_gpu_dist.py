@@ -58,9 +58,15 @@ def test_one_rank_distributed_paths_equal_plain_path():
     same(ref, single(*CFG, dist_mode="rccl1"))     # RCCL transport (dlopen'ed librccl), 1-rank communicator
 
 
-@pytest.mark.parametrize("world,ranker,metric,k", [(2, "LAMBDAMART", "NDCG", 10), (3, "LAMBDAMART", "NDCG", 10),
-                                                    (2, "MART", "NDCG", 10), (2, "LAMBDAMART", "MAP", 0), (3, "LAMBDAMART", "ERR", 10)])
-def test_k_shards_equal_one_shard(world, ranker, metric, k, tmp_path):
+CFG31 = (9000, 24, "mslr", 4, 31, 4)      # 30 growth steps allowed, trees finish after ~10: the ranks must stop enqueuing at the same step
+
+
+@pytest.mark.parametrize("world,ranker,metric,k,cfg", [(2, "LAMBDAMART", "NDCG", 10, CFG), (3, "LAMBDAMART", "NDCG", 10, CFG),
+                                                        (2, "MART", "NDCG", 10, CFG), (2, "LAMBDAMART", "MAP", 0, CFG),
+                                                        (3, "LAMBDAMART", "ERR", 10, CFG), (2, "LAMBDAMART", "NDCG", 10, CFG31),
+                                                        (3, "MART", "NDCG", 10, CFG31)])
+def test_k_shards_equal_one_shard(world, ranker, metric, k, cfg, tmp_path):
+    CFG = cfg
     ref = single(*CFG, ranker=ranker, metric=metric, k=k)
     out = str(tmp_path / "dist.npz")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
