@@ -100,6 +100,8 @@ struct Ctx {
     int32_t node_div, node_min;   // child-node histograms: target chunks per node, smallest chunk (see chunk_docs)
     int32_t n_live; const int32_t *live;   // unsharded runs: features with more than one distinct value (the others can never split); k_hist_finish
                                   // is launched over these only (a third of the Yahoo-shape columns are empty)
+    int32_t limb_words;           // sharded runs: int64 words per bin in the all-reduced histogram: 3 = (sum >> 44, sum & (2^44-1), count),
+                                  // 2 = ((sum >> 44) << 32 | count, low limb) when the data set has fewer than 2^25 documents
     int32_t fs_size;              // features a split attempt looks at: F, or (int)(rate * F) with feature sampling (Random Forests)
     unsigned long long seed;      // rl_params.seed
     int32_t mart, metric;    // MART leaf rule (learning/tree/MART.java); RL_METRIC_* of the train metric

@@ -457,14 +457,14 @@ static int enqueue_round(rl_trainer *t)
     if (fin_lds > 128 * 1024) return fail(RL_ERR_UNSUPPORTED, "too many features / leaves for the growth bookkeeping in LDS (feature sampling needs 64 bytes per feature)");
     if (t->dist) {
         hipLaunchKernelGGL(k_hist_reduce, dim3(c.F), dim3(kFinThreads), red_lds, s, c, 1);
-        int rcd = t->dist->allreduce(c.dist_buf, (size_t)c.F * c.TS * 3 + 4, DT_I64, OP_SUM, s);
+        int rcd = t->dist->allreduce(c.dist_buf, (size_t)c.F * c.TS * c.limb_words + 4, DT_I64, OP_SUM, s);
         if (rcd) return rcd;
         hipLaunchKernelGGL((k_hist_finish<true, true>), dim3(c.F), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
     } else hipLaunchKernelGGL((k_hist_finish<true, false>), dim3(c.n_live), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
     // Growth steps: each prepares up to kSpec queue nodes and commits as many splits as the fit loop allows; L-1 steps
     // always suffice (every step commits at least the head of the queue); finished trees make the rest no-ops.
     const int steps = std::max(c.L - 1, 1);
-    const size_t slot_words = (size_t)c.F * c.TS * 3 + 4;
+    const size_t slot_words = (size_t)c.F * c.TS * c.limb_words + 4;
     t->tree_seq++;
     bool throttle = c.progress != nullptr;
     for (int it = 0; it < steps; it++) {
@@ -1059,6 +1059,7 @@ int rl_init(rl_trainer *t)
             RL_HIP(t->pool.alloc(&t->d_qcat, (size_t)t->Qglobal)); RL_HIP(t->pool.alloc(&t->d_allQ, (size_t)t->n_ranks));
             RL_HIP(hipMemcpy(t->d_allQ, t->all_Q.data(), t->n_ranks * sizeof(int32_t), hipMemcpyHostToDevice));
             RL_HIP(hipMemset(t->d_qsend, 0, (size_t)t->Qmax * sizeof(double)));
+            c.limb_words = (t->Nglobal < (1ll << 25) && !getenv("RLHIP_LIMBS3")) ? 2 : 3;
             RL_HIP(t->pool.alloc(&c.dist_buf, ((size_t)F * TS * 3 + 4) * kSpec));
             RL_HIP(hipMemset(c.dist_buf, 0, ((size_t)F * TS * 3 + 4) * kSpec * sizeof(long long)));
         }
