@@ -175,6 +175,24 @@ int  rl_model_predict(rl_model *m, const float *X, int64_t n_docs, int32_t row_s
  * same per DataPoint on the CPU). */
 int  rl_model_predict_device(rl_model *m, const float *dX, int64_t n_docs, int32_t row_stride, float *dOut, void *stream);
 
+/* ---- LETOR text (host only) ---------------------------------------------------
+ * `label qid:ID fid:val ... # description` lines as learning/DataPoint.java:58-110 and features/FeatureManager.java:199-235 read
+ * them: lines are trimmed, empty ones and '#' comments skipped, the description is the text from '#', the qid / the values are
+ * the text after the LAST ':' of their token, values are Float.parseFloat (strtof: correctly rounded).  Every line that is not
+ * plain `number qid:token (digits:number)*` -- or that the reference rejects (negative label, feature id <= 0) -- is only
+ * FLAGGED (`slow`): the caller parses, or rejects, those lines itself, in file order.  `text` must outlive the handle. */
+typedef struct rl_letor rl_letor;
+int  rl_letor_parse(const char *text, int64_t len, rl_letor **out);
+int  rl_letor_info(const rl_letor *l, int64_t *n_docs, int32_t *max_fid, int64_t *n_slow);
+/* per data line (any pointer may be NULL): label, largest feature id, qid / description / whole trimmed line as (offset, length)
+ * into `text`, and the slow flag */
+int  rl_letor_arrays(const rl_letor *l, float *labels, int32_t *last_fid, int64_t *qid_off, int32_t *qid_len, int64_t *desc_off,
+                     int32_t *desc_len, int64_t *line_off, int32_t *line_len, uint8_t *slow);
+/* dense rows: X[i * row_stride + fid] = value, NaN where the line does not name the feature (DenseDataPoint's UNKNOWN);
+ * row_stride >= max_fid + 1; rows of flagged lines are all NaN */
+int  rl_letor_rows(const rl_letor *l, float *X, int64_t row_stride);
+void rl_letor_destroy(rl_letor *l);
+
 /* ---- multi-GPU (one process per GPU; queries sharded across ranks) ---------- */
 #define RL_UNIQUE_ID_BYTES 128
 int rl_dist_unique_id(void *id_out /* RL_UNIQUE_ID_BYTES */);       /* call on rank 0, broadcast out of band */

@@ -47,6 +47,7 @@ ABI_SYMBOLS = [
     "rl_finish", "rl_num_trees", "rl_get_tree", "rl_get_round_metrics", "rl_best_validation", "rl_predict",
     "rl_model_to_text", "rl_model_from_text", "rl_model_destroy", "rl_model_num_trees", "rl_model_features",
     "rl_model_predict", "rl_model_predict_device", "rl_dist_unique_id", "rl_dist_init", "rl_dist_init_callback", "rl_bin_stride", "rl_quant_exponent", "rl_get_array", "rl_debug_exp", "rl_debug_float_chain",
+    "rl_letor_parse", "rl_letor_info", "rl_letor_arrays", "rl_letor_rows", "rl_letor_destroy",
     "rl_get_timing", "rl_reset_timing",
 ]
 
@@ -103,6 +104,12 @@ def lib():
     L.rl_get_array.argtypes = [vp, i32, vp, i64]
     L.rl_debug_exp.argtypes = [vp, i32, vp, vp]
     L.rl_debug_float_chain.argtypes = [i32, vp, i64, vp, i32, vp, vp]
+    L.rl_letor_parse.argtypes = [vp, i64, C.POINTER(vp)]
+    L.rl_letor_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64)]
+    L.rl_letor_arrays.argtypes = [vp] * 10
+    L.rl_letor_rows.argtypes = [vp, vp, i64]
+    L.rl_letor_destroy.argtypes = [vp]
+    L.rl_letor_destroy.restype = None
     L.rl_get_timing.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
     L.rl_reset_timing.argtypes = [vp]
     _lib = L
@@ -153,6 +160,30 @@ def debug_exp(x):
     a, b = np.zeros_like(x), np.zeros_like(x)
     check(lib().rl_debug_exp(x.ctypes.data, len(x), a.ctypes.data, b.ctypes.data))
     return a, b
+
+
+def letor_parse(data):
+    """Native LETOR parser (rl_letor_*): `data` = the file's bytes.  Returns a dict of per-line arrays, the dense row matrix
+    (NaN = not named on the line) and the flags of the lines the caller has to parse itself."""
+    buf = C.create_string_buffer(data, len(data)) if not isinstance(data, C.Array) else data
+    h = C.c_void_p()
+    check(lib().rl_letor_parse(buf, len(data), C.byref(h)))
+    try:
+        n, mf, ns = C.c_int64(), C.c_int32(), C.c_int64()
+        check(lib().rl_letor_info(h, C.byref(n), C.byref(mf), C.byref(ns)))
+        n, mf = n.value, mf.value
+        out = dict(n=n, max_fid=mf, n_slow=ns.value, labels=np.zeros(n, np.float32), last_fid=np.zeros(n, np.int32),
+                   qid_off=np.zeros(n, np.int64), qid_len=np.zeros(n, np.int32), desc_off=np.zeros(n, np.int64), desc_len=np.zeros(n, np.int32),
+                   line_off=np.zeros(n, np.int64), line_len=np.zeros(n, np.int32), slow=np.zeros(n, np.uint8))
+        check(lib().rl_letor_arrays(h, *[out[k].ctypes.data for k in ("labels", "last_fid", "qid_off", "qid_len", "desc_off", "desc_len",
+                                                                       "line_off", "line_len", "slow")]))
+        X = np.empty((n, mf + 1), np.float32)
+        if n:
+            check(lib().rl_letor_rows(h, X.ctypes.data, mf + 1))
+        out["X"] = X
+        return out
+    finally:
+        lib().rl_letor_destroy(h)
 
 
 def debug_float_chain(x, seg_start=None, device=0):

@@ -19,6 +19,11 @@ class FeatureManager:
         samples = []
         countEntries = 0
         try:
+            fast = FeatureManager._read_native(inputFile, mustHaveRelDoc)
+            if fast is not None:
+                samples, countEntries = fast
+                logger.info("(%d ranked lists, %d entries read)", len(samples), countEntries)
+                return samples
             with smart_reader(inputFile) as f:
                 lastID, hasRel, rl = "", False, []
                 for content in f:
@@ -43,6 +48,54 @@ class FeatureManager:
         except Exception as ex:       # noqa: BLE001
             raise RankLibError("Error in FeatureManager::readInput(): %s" % ex)
         return samples
+
+    native = True                     # parse with librlhip's rl_letor_* (host code); False = the pure-Python reader below
+
+    @staticmethod
+    def _read_native(inputFile, mustHaveRelDoc):
+        """The same lists as the loop in readInput, with the lines parsed by rl_letor_parse on all host threads.  Lines the native
+        parser flags (anything but plain `number qid:token (digits:number)*`) go through DataPoint's own parser, in file order,
+        so malformed input raises exactly what it raised before."""
+        if not FeatureManager.native:
+            return None
+        try:
+            from . import _native as N
+            N.lib()
+        except Exception:             # noqa: BLE001 -- no library (e.g. a CPU-only checkout): the Python reader still works
+            return None
+        raw = (gzip.open(inputFile, "rb") if inputFile.endswith(".gz") else open(inputFile, "rb")).read()
+        try:
+            raw.decode("ascii")
+        except UnicodeDecodeError:    # non-ASCII text: offsets into the bytes would not be offsets into the str
+            return None
+        p = N.letor_parse(raw)
+        text = raw.decode("ascii")     # ASCII: byte offsets are character offsets
+        n, X, mf = p["n"], p["X"], p["max_fid"]
+        rows = list(X)                 # row views, created at C speed
+        labels, last, slow = p["labels"].tolist(), p["last_fid"].tolist(), p["slow"].tolist()
+        qo, do, lo = p["qid_off"].tolist(), p["desc_off"].tolist(), p["line_off"].tolist()
+        qe = (p["qid_off"] + p["qid_len"]).tolist()
+        de = (p["desc_off"] + p["desc_len"]).tolist()
+        le = (p["line_off"] + p["line_len"]).tolist()
+        from_parsed = DataPoint.from_parsed
+        samples, rl, lastID, hasRel = [], [], "", False
+        for i in range(n):
+            if slow[i]:
+                qp = DataPoint(text[lo[i]:le[i]])
+            else:
+                row = rows[i]
+                qp = from_parsed(labels[i], text[qo[i]:qe[i]], text[do[i]:de[i]], row if last[i] == mf else row[:last[i] + 1])
+            if lastID and lastID != qp.id:
+                if not mustHaveRelDoc or hasRel:
+                    samples.append(RankList(rl))
+                rl, hasRel = [], False
+            if qp.label > 0:
+                hasRel = True
+            lastID = qp.id
+            rl.append(qp)
+        if rl and (not mustHaveRelDoc or hasRel):
+            samples.append(RankList(rl))
+        return samples, n
 
     @staticmethod
     def readFeature(featureDefFile):

@@ -72,6 +72,17 @@ class DataPoint:
         except Exception as ex:       # noqa: BLE001 -- the reference wraps everything
             raise RankLibError("Error in DataPoint::parse() %s" % ex)
 
+    @classmethod
+    def from_parsed(cls, label, qid, description, fvals):
+        """a DataPoint from already parsed fields (features.FeatureManager.readInput's native path)"""
+        dp = cls.__new__(cls)
+        dp.label = label
+        dp.id = qid
+        dp.description = description
+        dp.fVals = fvals
+        dp.cached = -1.0
+        return dp
+
     def getFeatureValue(self, fid):   # learning/DenseDataPoint.java:21-32
         if fid <= 0 or fid >= len(self.fVals):
             if DataPoint.missingZero:

@@ -275,3 +275,71 @@ def test_random_forests_bags_match_the_oracle(tmp_path, rtype, frate, srate):
     back = learning.RankerFactory().loadRankerFromFile(path)
     assert back.name() == "Random Forests" and np.array_equal(np.array(back.evalList(allrows)), got)
     assert back.toString() == rf.toString() and open(path).read().startswith("## Random Forests\n## No. of bags = 3\n")
+
+
+def _same_lists(a, b):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert x.getID() == y.getID() and len(x) == len(y) and x.getFeatureCount() == y.getFeatureCount()
+        for p, q in zip(x.rl, y.rl):
+            assert p.label == q.label and p.id == q.id and p.description == q.description
+            assert np.array_equal(p.fVals.view(np.uint32), q.fVals.view(np.uint32))
+
+
+def test_native_letor_reader_equals_the_python_reader(tmp_path):
+    """rl_letor_* (host code in librlhip.so) parses the plain grammar on all host threads and hands every other line to
+    DataPoint's own parser: same lists, same values bit for bit, same errors (learning/DataPoint.java:58-110,
+    features/FeatureManager.java:199-235)."""
+    import gzip
+    rng = np.random.RandomState(9)
+    lines = ["# a comment line", "", "   \t  "]
+    for q in range(40):
+        for d in range(rng.randint(1, 9)):
+            feats = sorted(rng.choice(np.arange(1, 30), rng.randint(1, 12), replace=False))
+            toks = " ".join("%d:%s" % (f, rng.choice(["%.6f" % rng.randn(), "%e" % rng.rand(), "%d" % rng.randint(-5, 5), "+1.5", "007", ".25", "3."]))
+                            for f in feats)
+            sep = rng.choice([" ", "\t", "  "])
+            desc = rng.choice(["", " # doc %d_%d" % (q, d), "#x # y:1", "   #"])
+            lines.append(("%d%sqid:%s%s%s%s" % (rng.randint(0, 5), sep, rng.choice(["q%d" % q, "a:b:%d" % q]), sep, toks, desc)) + rng.choice(["", " ", "\r"]))
+    lines += ["2 qid:zz 1:nan 2:1e400 3:-Infinity 4:1E2 # odd floats go through the slow path", "1 qid:zz 5:1.5",
+              "0 qid:zz"]                                     # a line without features
+    f1 = tmp_path / "a.txt"
+    f1.write_text("\n".join(lines) + "\n")
+    with gzip.open(tmp_path / "a.txt.gz", "wt") as g:
+        g.write("\n".join(lines) + "\n")
+    ref = None
+    for native, path in ((False, f1), (True, f1), (True, tmp_path / "a.txt.gz")):
+        features.FeatureManager.native = native
+        try:
+            got = features.FeatureManager.readInput(str(path))
+        finally:
+            features.FeatureManager.native = True
+        if ref is None:
+            ref = got
+        else:
+            _same_lists(ref, got)
+    assert sum(len(r) for r in ref) == len([ln for ln in lines if ln.strip() and not ln.strip().startswith("#")])
+    # malformed lines raise what the Python reader raises, whichever line comes first
+    for bad, msg in (("-1 qid:1 1:0.5", "Relevance label cannot be negative"), ("1 qid:1 0:0.5", "less than or equal to zero"),
+                     ("1 qid:1 abc", "Error in DataPoint::parse()"), ("x qid:1 1:1", "Error in DataPoint::parse()")):
+        fb = tmp_path / "bad.txt"
+        fb.write_text("1 qid:0 1:1.0\n" + bad + "\n2 qid:1 1:2.0\n")
+        errs = []
+        for native in (False, True):
+            features.FeatureManager.native = native
+            try:
+                with pytest.raises(RankLibError) as e:
+                    features.FeatureManager.readInput(str(fb))
+                errs.append(str(e.value))
+            finally:
+                features.FeatureManager.native = True
+        assert errs[0] == errs[1] and msg in errs[0], errs
+    # mustHaveRelDoc drops the lists without a relevant document on both paths
+    f2 = tmp_path / "rel.txt"
+    f2.write_text("0 qid:a 1:1\n0 qid:a 1:2\n1 qid:b 1:3\n0 qid:c 1:4\n")
+    features.FeatureManager.native = False
+    r0 = features.FeatureManager.readInput(str(f2), True)
+    features.FeatureManager.native = True
+    r1 = features.FeatureManager.readInput(str(f2), True)
+    _same_lists(r0, r1)
+    assert [r.getID() for r in r1] == ["b"]
