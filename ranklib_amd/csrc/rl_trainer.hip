@@ -106,7 +106,7 @@ struct rl_trainer {
     std::vector<int32_t> all_N, all_Q;        // local sizes of every rank
     int64_t Nglobal = 0; int32_t Qglobal = 0, Qmax = 0;
     ChainBufs gchain;                          // float chains over the all-gathered leaf values
-    double *d_gx = nullptr; int32_t *d_gls = nullptr; int32_t lsstride = 0;
+    double *d_gx = nullptr; int32_t *d_gls = nullptr; int32_t lsstride = 0; float *d_gres = nullptr;
     double *d_qsend = nullptr, *d_qgath = nullptr, *d_qcat = nullptr; int32_t *d_allQ = nullptr;
 };
 
@@ -537,11 +537,17 @@ static int enqueue_round(rl_trainer *t)
         if (rcd) return rcd;
         rcd = t->dist->allgather(c.leaf_start, t->d_gls, (size_t)t->lsstride * sizeof(int32_t), s);
         if (rcd) return rcd;
-        hipLaunchKernelGGL(k_plan_global, dim3(1), dim3(64), 0, s, (const int32_t *)t->d_gls, t->n_ranks, t->lsstride, c.L, t->gchain);
+        hipLaunchKernelGGL(k_plan_global, dim3(1), dim3(64), 0, s, (const int32_t *)t->d_gls, t->n_ranks, t->lsstride, c.L, t->gchain, t->dist->rank);
         hipLaunchKernelGGL(k_chain_assemble, dim3(c.L, 2), dim3(kThreads), 0, s, (const double *)t->d_gx, (const int32_t *)t->d_gls, t->n_ranks, 2,
-                           (int)lb.cap_n, t->lsstride, c.L, t->gchain);
+                           (int)lb.cap_n, t->lsstride, c.L, t->gchain, t->dist->rank);
         ChainSource gsrc{t->gchain.xs, t->gchain.xs + t->gchain.cap_n, nullptr, nullptr, nullptr, nullptr};
         enqueue_chain(t, t->gchain, gsrc);
+        if (t->n_ranks > 1) {       // every rank evaluated its own leaves: exchange the 2 L float sums
+            rcd = t->dist->allgather(t->gchain.result, t->d_gres, (size_t)2 * t->gchain.maxseg * sizeof(float), s);
+            if (rcd) return rcd;
+            hipLaunchKernelGGL(k_chain_pick, dim3((2 * c.L + kThreads - 1) / kThreads), dim3(kThreads), 0, s, (const float *)t->d_gres, t->n_ranks, 2,
+                               t->gchain.maxseg, c.L, t->gchain.result);
+        }
         hipLaunchKernelGGL(k_leaf_output, dim3((c.L + kThreads - 1) / kThreads), dim3(kThreads), 0, s, c, t->gchain);
     } else {   // K7: the two Java float running sums of every leaf, exactly, in parallel (rl_chain.inc)
         ChainSource src{nullptr, nullptr, c.lw, c.idx[0], c.idx[1], t->d_seg_buf};
@@ -1055,6 +1061,7 @@ int rl_init(rl_trainer *t)
             t->lsstride = c.MAXN + 2;
             RL_HIP(t->pool.alloc(&t->d_gx, (size_t)t->n_ranks * 2 * t->leaf_chain.cap_n));
             RL_HIP(t->pool.alloc(&t->d_gls, (size_t)t->n_ranks * t->lsstride));
+            RL_HIP(t->pool.alloc(&t->d_gres, (size_t)t->n_ranks * 2 * (c.MAXN + 1) + 8));
             RL_HIP(t->pool.alloc(&t->d_qsend, (size_t)t->Qmax)); RL_HIP(t->pool.alloc(&t->d_qgath, (size_t)t->n_ranks * t->Qmax));
             RL_HIP(t->pool.alloc(&t->d_qcat, (size_t)t->Qglobal)); RL_HIP(t->pool.alloc(&t->d_allQ, (size_t)t->n_ranks));
             RL_HIP(hipMemcpy(t->d_allQ, t->all_Q.data(), t->n_ranks * sizeof(int32_t), hipMemcpyHostToDevice));
