@@ -7,6 +7,8 @@ implied, and asserted with == on the float-accumulated per-round value.
 """
 from fractions import Fraction
 
+import os
+
 import numpy as np
 import pytest
 
@@ -589,3 +591,16 @@ def test_sparse_700_feature_shape_matches_the_oracle():
         assert_same_tree(to, tg, X, "round %d" % r)
         assert np.array_equal(g.array("SCORE").view(np.int64), o.scores().view(np.int64))
         assert np.float32(tmo).view(np.uint32) == np.float32(tmg).view(np.uint32)
+
+
+@pytest.mark.gpu
+def test_fuzz_of_small_configurations_has_no_unexplained_mismatch():
+    """tools/fuzz_parity.py: 300 random configurations (rankers x metrics x cut-offs x leaves x mls x -tc x feature sampling x list
+    lengths); wherever the GPU's and the oracle's trees part, the tool must be able to verify a tie situation of DESIGN.md 1 in
+    rational arithmetic -- anything else is a mismatch and fails the run."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "300", "2024"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "300 cases: 0 mismatches" in r.stdout, r.stdout[-500:]
