@@ -163,6 +163,12 @@ for case in range(n_cases):
         else:
             so, _ = o.finish(); sg, _ = g.finish()
             assert so == sg, "final metric"
+            # the saved model, loaded back and scored by the inference kernel == Ensemble.eval of the oracle's trees on the training rows
+            mdl = N.Model(g.model_text())
+            rows = np.concatenate([np.zeros((n, 1), np.float32), X], axis=1)
+            got, want = mdl.predict_rows(rows), o.predict(X)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "model scores"
+            mdl.close()
     except N.RankLibError as ex:
         if "rlhip status -4" in str(ex):          # a documented limit (e.g. -tc -1 with more than 4095 distinct values)
             skipped += 1
