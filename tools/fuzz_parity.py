@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Random small configurations, GPU against the oracle: rankers x metrics x cut-offs x leaves x min leaf support x threshold
-candidates x feature sampling x list-length mixes x validation.  usage (GPU box): python tools/fuzz_parity.py [n_cases] [seed]"""
+candidates x feature sampling x list-length mixes x validation.  usage (GPU box): python tools/fuzz_parity.py [n_cases] [seed] [scale]"""
 import os
 import sys
 
@@ -101,6 +101,7 @@ def classify(to, tg, X, lam, sampling):
 
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1          # multiplies the number of lists (bigger data: several chunks / tiles per node)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = ties = skipped = 0
 reasons = {}
@@ -113,6 +114,8 @@ for case in range(n_cases):
         sizes = np.concatenate([rng.integers(1, 17, 100), rng.integers(17, 200, 30), rng.integers(200, 500, 3)])
     else:
         sizes = rng.integers(100, 700, int(rng.integers(3, 12)))
+    if scale > 1:
+        sizes = np.concatenate([sizes] * scale)
     rng.shuffle(sizes)
     qoff = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
     n = int(qoff[-1])
