@@ -142,6 +142,8 @@ for case in range(n_cases):
         g = N.Trainer(n_trees=rounds, n_leaves=leaves, learning_rate=lr, n_threshold=tc, min_leaf_support=mls, metric_k=k, metric=str(metric),
                       ranker=str(ranker), feature_sampling_rate=frate, seed=seed)
         g.set_train(X, lab, qoff)
+        if os.environ.get("FUZZ_DIST"):        # the sharded code path (count + scatter, limb reduce, finish<.,true>, gathered chains) with one rank
+            g.dist_init_callback(0, 1, lambda arr, op: None, lambda src: src.copy())
         o.init(); g.init()
         for m in range(rounds):
             to, tmo, _, _ = o.round()
