@@ -135,22 +135,35 @@ for case in range(n_cases):
     lr = float(rng.choice([0.1, 0.05, 1.0]))
     rounds = int(rng.integers(2, 6))
     seed = int(rng.integers(0, 2 ** 31))
-    desc = dict(case=case, n=n, F=F, kind=str(kind), ranker=str(ranker), metric=str(metric), k=k, leaves=leaves, mls=mls, tc=tc, frate=frate, lr=lr, rounds=rounds)
+    with_valid = bool(rng.random() < 0.3) and not os.environ.get("FUZZ_DIST")      # a validation set + early stopping
+    estop = int(rng.choice([1, 2, 100]))
+    if with_valid:
+        vs = rng.integers(1, 60, int(rng.integers(5, 60)))
+        vqoff = np.concatenate([[0], np.cumsum(vs)]).astype(np.int32)
+        Xv = rng.random((int(vqoff[-1]), F)).astype(np.float32)
+        Xv[:, ::3] = np.floor(Xv[:, ::3] * 7)
+        labv = np.floor(rng.random(int(vqoff[-1])) * 5).astype(np.float32)
+    desc = dict(case=case, n=n, F=F, kind=str(kind), ranker=str(ranker), metric=str(metric), k=k, leaves=leaves, mls=mls, tc=tc, frate=frate, lr=lr, rounds=rounds, valid=with_valid, estop=estop)
     try:
         o = O.Oracle(X, lab, qoff, n_trees=rounds, n_leaves=leaves, lr=lr, n_threshold=tc, mls=mls, k=k, ranker=str(ranker), metric=str(metric),
-                     n_threads=3, frate=frate, seed=seed)
+                     n_threads=3, frate=frate, seed=seed, early_stop=estop)
         g = N.Trainer(n_trees=rounds, n_leaves=leaves, learning_rate=lr, n_threshold=tc, min_leaf_support=mls, metric_k=k, metric=str(metric),
-                      ranker=str(ranker), feature_sampling_rate=frate, seed=seed)
+                      ranker=str(ranker), feature_sampling_rate=frate, seed=seed, early_stop_rounds=estop)
         g.set_train(X, lab, qoff)
+        if with_valid:
+            o.set_validation(Xv, labv, vqoff); g.set_validation(Xv, labv, vqoff)
         if os.environ.get("FUZZ_DIST"):        # the sharded code path (count + scatter, limb reduce, finish<.,true>, gathered chains) with one rank
             g.dist_init_callback(0, 1, lambda arr, op: None, lambda src: src.copy())
         o.init(); g.init()
+        same_trees = True                 # validation rows may take another branch at a tie-resolved (equivalent, not identical) split
+        ended = False                     # left the case at a tie / a diverged run
         for m in range(rounds):
-            to, tmo, _, _ = o.round()
-            tg, tmg, _, _ = g.boost_round()
+            to, tmo, vmo, so_ = o.round()
+            tg, tmg, vmg, sg_ = g.boost_round()
             lam = o.lambdas().copy()
             if not np.isfinite(o.scores()).all() or not np.isfinite(lam).all():
                 skipped += 1                      # the run has diverged to infinite scores: out of contract
+                ended = True
                 break
             assert np.array_equal(g.array("LAMBDA"), lam), "lambda, round %d" % m
             try:
@@ -160,20 +173,32 @@ for case in range(n_cases):
                 if why:
                     ties += 1
                     reasons[why] = reasons.get(why, 0) + 1
+                    ended = True
                     break
                 print("  unexplained:", getattr(classify, "last", None), flush=True)
                 raise
             assert np.array_equal(g.array("SCORE"), o.scores()), "scores, round %d" % m
             assert np.float32(tmg) == np.float32(tmo), "metric, round %d" % m
-        else:
-            so, _ = o.finish(); sg, _ = g.finish()
-            assert so == sg, "final metric"
+            ta, tb = to.trimmed(), tg.trimmed()
+            same_trees = same_trees and np.array_equal(ta["feature"], tb["feature"]) and np.array_equal(ta["threshold"].view(np.uint32), tb["threshold"].view(np.uint32))
+            if with_valid and same_trees:
+                assert np.float32(vmg) == np.float32(vmo), "validation metric, round %d" % m
+                assert so_ == sg_, "early stop flag, round %d" % m
+            if so_ or sg_:
+                break                             # early stop (LambdaMART.java:248)
+        if not ended:
+            so, vo = o.finish(); sg, vg = g.finish()
+            if not with_valid or same_trees:
+                assert so == sg, "final metric"
+                if with_valid:
+                    assert vo == vg and o.trees_kept() == g.num_trees(), "validation: final metric / kept trees (rollback)"
             # the saved model, loaded back and scored by the inference kernel == Ensemble.eval of the oracle's trees on the training rows
-            mdl = N.Model(g.model_text())
-            rows = np.concatenate([np.zeros((n, 1), np.float32), X], axis=1)
-            got, want = mdl.predict_rows(rows), o.predict(X)
-            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "model scores"
-            mdl.close()
+            if not with_valid or same_trees:      # (with equivalent-but-not-identical trees the validation rows may pick another best round)
+                mdl = N.Model(g.model_text())
+                rows = np.concatenate([np.zeros((n, 1), np.float32), X], axis=1)
+                got, want = mdl.predict_rows(rows), o.predict(X)
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "model scores"
+                mdl.close()
     except N.RankLibError as ex:
         if "rlhip status -4" in str(ex):          # a documented limit (e.g. -tc -1 with more than 4095 distinct values)
             skipped += 1
