@@ -10,14 +10,23 @@ import sys
 
 def main():
     db = sys.argv[1]
-    first = sys.argv[2] if len(sys.argv) > 2 else "k_lambda_fused<128>"
+    first = sys.argv[2] if len(sys.argv) > 2 else None
     con = sqlite3.connect(db)
     rows = list(con.execute("select name, start, end from kernels order by start"))
-    starts = [i for i, r in enumerate(rows) if first in r[0]]
-    if not starts:
-        print("no kernel matching", first)
-        return
-    i0 = starts[-1]
+    if first:
+        starts = [i for i, r in enumerate(rows) if first in r[0]]
+        if not starts:
+            print("no kernel matching", first)
+            return
+        i0 = starts[-1]
+    else:       # a round starts with its lambda kernels (whichever variants the data set uses) and k_max_reduce, then k_quantize
+        qs = [i for i, r in enumerate(rows) if "k_quantize" in r[0]]
+        if not qs:
+            print("no k_quantize launch in the trace")
+            return
+        i0 = qs[-1]
+        while i0 > 0 and any(x in rows[i0 - 1][0] for x in ("k_lambda_", "k_max_reduce", "k_pair_terms", "k_mart_residual")):
+            i0 -= 1
     t0 = rows[i0][1]
     prev_end = t0
     busy = 0
