@@ -65,8 +65,15 @@ enum {                                  /* rl_params.flags */
                                            running sums (learning/tree/LambdaMART.java:401-408).  NOT parity. */
     RL_FLAG_TIMING = 2,                 /* record HIP events around the root histogram and the lambda kernels (rl_get_timing) */
     RL_FLAG_TIMING_NODES = 8,           /* ... and around every growth step's node-histogram launch (30 event pairs per round) */
-    RL_FLAG_SERIAL_CHAIN = 4            /* evaluate the float running sums with the literal serial kernel instead of
+    RL_FLAG_SERIAL_CHAIN = 4,           /* evaluate the float running sums with the literal serial kernel instead of
                                            the exact parallel scheme (same results; for cross-checks) */
+    RL_FLAG_JAVA_ORDER = 16             /* strict mode: split gains and node deviances come from the f64 histogram RankLib itself
+                                           would hold -- every (feature, bin) sum accumulated sequentially in ascending sample
+                                           order (FeatureHistogram.java:126-146,166-195), sequential prefix, right sibling =
+                                           parent - left on the cumulative arrays (:222-234), sumResponse / sqSumResponse as
+                                           :133-137,182-186,202-203 -- so the arg-max of :236-264,302-309 lands on the candidate
+                                           the Java picks even where exact arithmetic ties.  Same trees, several
+                                           times slower (the sums are serial chains); one GPU only. */
 };
 
 typedef struct rl_trainer rl_trainer;   /* opaque */
@@ -231,6 +238,8 @@ enum {
     RL_ARR_CHAIN_MISS = 14,     /* int32[2*(2*n_leaves)]: per (value array, leaf slot) window misses of the last round */
     RL_ARR_GROW_STATS = 15,     /* int32[4] cumulative: growth steps run, nodes prepared (partition + child histograms),
                                    splits committed to trees, trees grown -- speculative best-first growth */
+    RL_ARR_ROOT_SUM_JAVA = 17,  /* double[n_features*stride]   with RL_FLAG_JAVA_ORDER: cumulative root sums of the last round in the
+                                   Java's own accumulation order (== FeatureHistogram.sum of the root, bit for bit) */
     RL_ARR_PHASE_CLOCKS = 16    /* int64[64][16] device wall-clock stamps (10 ns) inside the last 64 growth steps; all zero unless the
                                    library was built with -DRL_PHASE_CLOCKS (tools/phase_clocks.py) */
 };

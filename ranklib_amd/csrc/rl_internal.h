@@ -97,6 +97,7 @@ struct Ctx {
     int32_t N, Npad, Q, F, TS, L, MAXN, NC, mls, k, maxChunks, nTiles, FG, numFG;   // MAXN = 2L-1 tree nodes, NC = node records incl. speculation
     float lr;
     int32_t rank, n_ranks;
+    int32_t Nglobal;              // documents over ALL ranks (== N on one GPU): fixes the lambda^2 exponent, which every rank must share
     int32_t node_div, node_min;   // child-node histograms: target chunks per node, smallest chunk (see chunk_docs)
     int32_t n_live; const int32_t *live;   // unsharded runs: features with more than one distinct value (the others can never split); k_hist_finish
                                   // is launched over these only (a third of the Yahoo-shape columns are empty)
@@ -143,6 +144,14 @@ struct Ctx {
     // host-visible (pinned, fine-grained) growth progress: tree_seq << 32 | select_step calls in the tree << 1 | done.
     // A HINT only: the host uses it to stop enqueuing growth steps of a finished tree (extra steps are no-ops).
     unsigned long long *progress;
+    // RL_FLAG_JAVA_ORDER (rl_java_order.inc): the f64 histogram RankLib itself would hold -- per-(feature, bin) sums accumulated
+    // sequentially in ascending document order, sequential prefix, right = parent - left -- decides the splits
+    int32_t java;
+    double *jl;              // [N]        lambda in sample-list order of the nodes being built (left children / the root)
+    uint16_t *jb;            // [F][Npad]  bins in the same order, feature-major
+    double *jbin;            // [kSpec][F][TS] per-bin Java-order sums of each slot's LEFT child (slot 0: the root pass)
+    double *jtot;            // [kSpec][2]  sumResponse, sqSumResponse of the same nodes (FeatureHistogram.java:133-137,182-186)
+    double *jcum;            // [NC][F][TS] cumulative Java-order sums of every live node
     long long *clk;          // [64][16] wall-clock stamps (10 ns units) of the finish / select phases of the last 64 growth steps; only
                              // written by builds with -DRL_PHASE_CLOCKS (tools/phase_clocks.py), RL_ARR_PHASE_CLOCKS reads it
 };

@@ -1031,7 +1031,7 @@ int rl_init(rl_trainer *t)
     RL_HIP(t->pool.alloc(&t->d_mean, (size_t)2));
     {
         int64_t Nmax = N;
-        t->Qglobal = t->tr.Q; t->Qmax = t->tr.Q; t->Nglobal = N;
+        t->Qglobal = t->tr.Q; t->Qmax = t->tr.Q; t->Nglobal = N; c.Nglobal = N;
         if (t->dist) {      // sizes of every rank
             if (t->has_valid) return fail(RL_ERR_UNSUPPORTED, "validation data with multi-GPU training is not built yet");
             int32_t *d_sz = nullptr, *d_all = nullptr;
@@ -1049,6 +1049,7 @@ int rl_init(rl_trainer *t)
                 Nmax = std::max<int64_t>(Nmax, all[2 * r]); t->Qmax = std::max(t->Qmax, all[2 * r + 1]);
             }
             if (t->Nglobal >= (int64_t)2147483647 - 4096) return fail(RL_ERR_UNSUPPORTED, "more than 2^31 documents in total");
+            c.Nglobal = (int32_t)t->Nglobal;
         }
         int rc = alloc_chain(t, t->leaf_chain, c.MAXN + 1, 2, Nmax, true);
         if (rc) return rc;

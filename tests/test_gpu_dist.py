@@ -45,6 +45,7 @@ def same(a, b):
     for x, y in zip(ta, tb):
         for k in ("feature", "left", "right", "count"):
             assert np.array_equal(x[k], y[k]), k
+        assert np.array_equal(x["deviance"].view(np.int64), y["deviance"].view(np.int64))      # exact sums of lambda and lambda^2: rank-count invariant
         assert np.array_equal(x["threshold"].view(np.uint32), y["threshold"].view(np.uint32))
         assert np.array_equal(x["output"].view(np.uint32), y["output"].view(np.uint32))
 
@@ -58,13 +59,23 @@ def test_one_rank_distributed_paths_equal_plain_path():
     same(ref, single(*CFG, dist_mode="rccl1"))     # RCCL transport (dlopen'ed librccl), 1-rank communicator
 
 
+CFG2K = (16384, 24, "ns", 3, 12, 4)       # shards of 8199 / 8185 documents: different ceil(log2(N + 1)), one lambda^2 scale for all ranks
+
+
+def test_shard_sizes_straddle_a_power_of_two():
+    from ranklib_amd import dist as D
+    X, lab, qoff = synth.make_dataset(*CFG2K[:3], seed_offset=CFG2K[3])
+    sizes = [D.shard(X, lab, qoff, r, 2)[0].shape[0] for r in range(2)]
+    assert min(sizes) < 8191 < max(sizes), sizes
+
+
 CFG31 = (9000, 24, "mslr", 4, 31, 4)      # 30 growth steps allowed, trees finish after ~10: the ranks must stop enqueuing at the same step
 
 
 @pytest.mark.parametrize("world,ranker,metric,k,cfg", [(2, "LAMBDAMART", "NDCG", 10, CFG), (3, "LAMBDAMART", "NDCG", 10, CFG),
                                                         (2, "MART", "NDCG", 10, CFG), (2, "LAMBDAMART", "MAP", 0, CFG),
                                                         (3, "LAMBDAMART", "ERR", 10, CFG), (2, "LAMBDAMART", "NDCG", 10, CFG31),
-                                                        (3, "MART", "NDCG", 10, CFG31)])
+                                                        (3, "MART", "NDCG", 10, CFG31), (2, "LAMBDAMART", "NDCG", 10, CFG2K)])
 def test_k_shards_equal_one_shard(world, ranker, metric, k, cfg, tmp_path):
     CFG = cfg
     ref = single(*CFG, ranker=ranker, metric=metric, k=k)

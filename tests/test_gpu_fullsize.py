@@ -1,4 +1,5 @@
-"""-m gpu: size-independent properties at BASELINE.json's full sizes (the oracle would take minutes there).
+"""-m gpu: BASELINE.json's full sizes (c1, c2): the oracle itself on all host threads (test_fullsize_oracle_parity: a few
+seconds of init + ~2 s per round on the GPU box's 256 threads) and size-independent properties.
 
 c1 = MSLR-WEB10K-shape (1.2 M docs), c2 = MSLR-WEB30K-shape (3.77 M docs), both 136 features / 31 leaves.
 Checked per round:
@@ -9,13 +10,16 @@ Checked per round:
   * score update: every document moved by exactly lr * (output of the leaf it fell into)
   * determinism: a second run from scratch produces byte-identical trees / scores
 """
+import os
+import time
+
 import numpy as np
 import pytest
 
 import oracle_ffi as O
 from ranklib_amd import _native as N
 from ranklib_amd import synth
-from tree_equiv import node_members
+from tree_equiv import assert_equivalent, node_members
 
 pytestmark = pytest.mark.gpu
 
@@ -91,3 +95,46 @@ def test_fullsize_determinism_c1():
         assert np.array_equal(x["score"].view(np.int64), y["score"].view(np.int64))
         for k in ("feature", "threshold", "left", "right", "output", "count"):
             assert np.array_equal(x["tree"][k], y["tree"][k])
+
+
+@pytest.mark.parametrize("shape,rounds", [("c1", 3), ("c2", 3)])
+def test_fullsize_oracle_parity(shape, rounds):
+    """c1 / c2 against the CPU oracle run with RankLib's MyThreadPool work split on every host thread
+    (learning/tree/LambdaMART.java:169-272): thresholds, bins, root counts at init; lambda, weight, scores, per-round metric
+    bit for bit; trees through tree_equiv (prints how many of the compared splits were exact-arithmetic ties that the two sides
+    resolved differently).  With RLHIP_TEST_JAVA_ORDER=1 the GPU runs RL_FLAG_JAVA_ORDER and the tie count must be 0."""
+    n_docs, n_feat, kind, _, n_leaves = synth.SHAPES[shape]
+    X, lab, qoff, Q = synth.make_shard(n_docs, n_feat, kind, 0, 1)
+    strict = os.environ.get("RLHIP_TEST_JAVA_ORDER", "0") == "1"
+    t0 = time.time()
+    o = O.Oracle(X, lab, qoff, n_trees=rounds, n_leaves=n_leaves, n_threads=os.cpu_count() or 8)
+    o.init()
+    t_oinit = time.time() - t0
+    g = N.Trainer(n_trees=rounds, n_leaves=n_leaves, **({"flags": N.RL_FLAG_JAVA_ORDER} if strict else {}))
+    g.set_train(X, lab, qoff)
+    g.init()
+    nb, thr, bins, cnt = g.array("NBINS"), g.array("THRESHOLDS"), g.array("BINS"), g.array("ROOT_COUNT")
+    for f in range(n_feat):
+        T = o.n_bins(f)
+        assert nb[f] == T, f
+        assert np.array_equal(thr[f, :T].view(np.uint32), o.thresholds(f).view(np.uint32)), f
+        assert np.array_equal(bins[f].astype(np.int32), o.bins(f)), f
+        assert np.array_equal(cnt[f, :T], o.root_count(f)), f
+    del bins
+    stats = {}
+    t_or = 0.0
+    for r in range(rounds):
+        t0 = time.time()
+        to, tmo, _, _ = o.round()
+        t_or += time.time() - t0
+        tg, tmg, _, _ = g.boost_round()
+        assert np.array_equal(g.array("LAMBDA").view(np.int64), o.lambdas().view(np.int64)), r
+        assert np.array_equal(g.array("WEIGHT").view(np.int64), o.weights().view(np.int64)), r
+        assert_equivalent(to, tg, X, "%s round %d trace %s" % (shape, r, o.split_trace()), stats)
+        assert np.float32(tmo).view(np.uint32) == np.float32(tmg).view(np.uint32), r
+        assert np.array_equal(g.array("SCORE").view(np.int64), o.scores().view(np.int64)), r
+    print("\n[fullsize parity] %s%s: %d rounds, splits compared %d, tie-resolved differently %d; oracle init %.1f s, %.2f s/round on %d threads"
+          % (shape, " (java-order)" if strict else "", rounds, stats.get("splits", 0), stats.get("plateau", 0), t_oinit,
+             t_or / rounds, os.cpu_count() or 8))
+    if strict:
+        assert stats.get("plateau", 0) == 0
