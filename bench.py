@@ -32,14 +32,42 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s measured float4 copy
 
 
-def pmc_traffic(shape, world):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass (profiles/r01_pmc_root_hist.json:
-    2 x FETCH_SIZE (gfx950 half-count correction) + WRITE_SIZE); null when no pass exists for this workload."""
+# rocprofv3 FETCH_SIZE -> bytes on gfx950, calibrated on known byte counts with this library's own access patterns
+# (tools/calib_fetch.sh, profiles/r02_fetch_calibration.txt): the counter tallies half of the bytes of 16-byte-per-lane streams AND of
+# 32-byte row gathers; WRITE_SIZE is exact.  Both in KB.
+FETCH_FACTOR_WIDE = 2.0
+FETCH_FACTOR_GATHER32 = 2.0
+
+
+def live_pmc(shape, rounds=4):
+    """HBM traffic of the histogram kernels, MEASURED by this run: bench.py re-runs itself (a few rounds, --plain) under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, kernel trace only, as MI355X_MICROARCH.md prescribes) and
+    reads the per-dispatch counters.  Returns None when rocprofv3 is not usable (the field is then null, never a stale number)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    res = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_root_hist.json")) as f:
-            d = json.load(f)
-        return float(d[shape]["traffic_bytes"]) if world == 1 and shape in d else None
-    except Exception:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="rlhip_pmc_", dir="/tmp")
+            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                   "--shape", shape, "--steps", str(rounds - 1), "--warmup", "1", "--plain"]
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=420, check=True)
+            con = sqlite3.connect(glob.glob(os.path.join(d, "**", "*.db"), recursive=True)[0])
+            for name, n, tot in con.execute("select kernel_name, count(*), sum(value) from counters_collection where counter_name=? group by kernel_name", (ctr,)):
+                if "k_hist<true" in name:
+                    res["root_" + ctr] = tot / n * 1024.0                  # per launch
+                elif "k_hist<false" in name:
+                    res["node_" + ctr] = tot / rounds * 1024.0            # per round (all growth steps)
+            con.close()
+            shutil.rmtree(d, ignore_errors=True)
+        return res if "root_FETCH_SIZE" in res and "root_WRITE_SIZE" in res else None
+    except Exception as ex:      # noqa: BLE001
+        sys.stderr.write("live PMC pass failed: %r\n" % (ex,))
         return None
 
 
@@ -151,11 +179,18 @@ def main():
     ap.add_argument("--cpu-rounds", type=int, default=8, help="rounds timed for the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores (RankLib's default -thread)")
     ap.add_argument("--no-timing", action="store_true", help="do not record HIP events around the dominant kernel")
+    ap.add_argument("--sustain", type=int, default=300, help="extra rounds after the timed region for config.sustained_rounds_per_s (0 = skip)")
+    ap.add_argument("--node-rounds", type=int, default=10, help="extra rounds with HIP events around every child-node histogram launch (0 = skip)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes behind roofline.traffic")
+    ap.add_argument("--plain", action="store_true", help="timed region only: no CPU baseline, sustained run, node timing, membench or PMC passes")
+    ap.add_argument("--java-order", action="store_true", help="RL_FLAG_JAVA_ORDER: the strict mode (split gains from the Java's own f64 summation order)")
     ap.add_argument("--workload", default="train", help="train (default, the BASELINE.json metric) | infer (configs[4]: Ensemble.eval)")
     ap.add_argument("--trees", type=int, default=10000, help="infer: trees in the scored model")
     ap.add_argument("--docs", type=int, default=10000000, help="infer: rows per step (54.8 GB at the 100 M of configs[4])")
     ap.add_argument("--infer-train-rounds", type=int, default=100)
     args = ap.parse_args()
+    if args.plain:
+        args.cpu_rounds, args.sustain, args.node_rounds, args.no_pmc, args.no_timing = 0, 0, 0, True, True
     if args.workload == "infer":
         if not any(a.startswith("--steps") for a in sys.argv):
             args.steps, args.warmup = 3, 1
@@ -190,8 +225,11 @@ def main():
     t_gen = time.time() - t0
 
     flags = 0 if args.no_timing else N.RL_FLAG_TIMING
+    if args.java_order:
+        flags |= N.RL_FLAG_JAVA_ORDER
+        args.sustain = min(args.sustain, 20)
     total_rounds = args.warmup + args.steps
-    g = N.Trainer(n_trees=max(total_rounds, 1), n_leaves=n_leaves, device=local_rank, flags=flags)
+    g = N.Trainer(n_trees=max(total_rounds + args.sustain + args.node_rounds, 1), n_leaves=n_leaves, device=local_rank, flags=flags)
     t0 = time.time()
     g.set_train(X, lab, qoff)
     if world > 1:
@@ -210,6 +248,7 @@ def main():
         g.boost_rounds_async(args.warmup)
         g.sync()
     g.reset_timing()
+    gd0 = g.array("GROW_DOCS").astype(np.float64)
     barrier()
     t0 = time.perf_counter()
     g.boost_rounds_async(args.steps)
@@ -223,9 +262,31 @@ def main():
 
     ndcg_t = float(g.round_metrics(total_rounds - 1)[0])
     ms_root, n_root, bytes_root = g.timing("HIST_ROOT")
-    ms_node, n_node, _ = g.timing("HIST_NODE")
     ms_lam, n_lam, _ = g.timing("LAMBDA")
     gs = g.array("GROW_STATS")
+    gd = (g.array("GROW_DOCS").astype(np.float64) - gd0) / max(args.steps, 1)      # documents per round: built, partitioned, Java-left, Java-split
+
+    # ---- after the headline region: sustained rate over a long run, then a few rounds with events around every node-histogram launch
+    sustained = None
+    if args.sustain > 0:
+        g.set_timing_flags(0)
+        barrier()
+        t1 = time.perf_counter()
+        g.boost_rounds_async(args.sustain)
+        g.sync()
+        barrier()
+        sustained = args.sustain / (time.perf_counter() - t1)
+    node = None
+    if args.node_rounds > 0 and not args.no_timing:
+        g.set_timing_flags(N.RL_FLAG_TIMING | N.RL_FLAG_TIMING_NODES)
+        g.reset_timing()
+        gdn0 = g.array("GROW_DOCS").astype(np.float64)
+        g.boost_rounds_async(args.node_rounds)
+        g.sync()
+        ms_node, n_node, _ = g.timing("HIST_NODE")
+        built = (g.array("GROW_DOCS").astype(np.float64) - gdn0)[0]
+        node = {"ms_per_round": ms_node / args.node_rounds, "launches_per_round": n_node / args.node_rounds,
+                "docs_per_round": built / args.node_rounds}
 
     if rank != 0:
         return
@@ -257,18 +318,65 @@ def main():
             "splits_per_tree": round(float(gs[2]) / max(int(gs[3]), 1), 2),
         },
     }
+    N_loc, F_, L_ = float(X.shape[0]), float(n_feat), float(n_leaves)
+    T_ = float(g.bin_stride())
+    rho_java, nu_java = gd[2] / max(float(n_docs), 1.0), gd[3] / max(float(n_docs), 1.0)      # global counts (every rank sees the same tree)
+    rho_built, nu_part = gd[0] / max(float(n_docs), 1.0), gd[1] / max(float(n_docs), 1.0)
+
+    def b_round(rho, nu, n):      # SURVEY.md 8d, b = 2 bytes per bin id
+        return (n * F_ * 2 * (1 + rho) + n * 8 * (1 + rho) + n * 4 * rho + nu * n * (2 + 4 + 4) + n * 28 + n * 20 + n * 16 + n * 12 +
+                (2 * L_ - 1) * F_ * T_ * 12)
+    copy_gbs = read_gbs = gather_gbs = None
+    if not args.plain:
+        try:        # the box's own rates with this library's kernels (2 GiB copy, 4 GiB read / 32-byte row gathers of a quarter of the rows)
+            ms_c, b_c = N.membench(0, 2 << 30, 1, 5, local_rank); copy_gbs = b_c / ms_c / 1e6
+            ms_r, b_r = N.membench(1, 4 << 30, 1, 5, local_rank); read_gbs = b_r / ms_r / 1e6
+            ms_g, b_g = N.membench(3, 4 << 30, 4, 5, local_rank); gather_gbs = b_g / ms_g / 1e6
+        except Exception as ex:       # noqa: BLE001
+            sys.stderr.write("membench failed: %r\n" % (ex,))
+    pmc = None if (args.no_pmc or world != 1) else live_pmc(args.shape)
     if n_root > 0:
         per_launch_ms = ms_root / n_root
         alg_bytes = bytes_root / n_root
         achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
+        B8d, Bbuilt = b_round(rho_java, nu_java, float(n_docs)), b_round(rho_built, nu_part, float(n_docs))
         out["roofline"] = {
             "kernel": "rl::k_hist<true,16> (root histogram, FeatureHistogram.update)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(args.shape, world),
+            "traffic": (FETCH_FACTOR_WIDE * pmc["root_FETCH_SIZE"] + pmc["root_WRITE_SIZE"]) if pmc else None,
+            "traffic_source": ("live: bench.py re-ran itself under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); bytes = "
+                               "%.1f x FETCH_SIZE + WRITE_SIZE per launch (factors: profiles/r02_fetch_calibration.txt)" % FETCH_FACTOR_WIDE) if pmc else None,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": per_launch_ms, "launches": int(n_root),
             "note": "algorithmic bytes = N_local*(F*2 B bin ids + 8 B fixed-point lambda); HIP events on the library stream",
+            "measured_copy_GBps": copy_gbs, "measured_read_GBps": read_gbs, "measured_gather32_GBps": gather_gbs,
+            "frac_of_measured_read": (achieved / read_gbs) if read_gbs else None,
+            # the whole round against HBM.  rho / nu as the survey defines them (what the JAVA accumulates / partitions:
+            # left children of the committed splits) and as this build moves them (smaller child of every PREPARED node, speculation included)
+            "round": {
+                "rho_java": rho_java, "nu_java": nu_java, "rho_built": rho_built, "nu_partitioned": nu_part,
+                "B_round_8d_bytes": B8d, "B_round_built_bytes": Bbuilt,
+                "round_frac_8d": B8d * rounds_per_s / (HBM_PEAK_GBS * 1e9), "round_frac_built": Bbuilt * rounds_per_s / (HBM_PEAK_GBS * 1e9),
+                "round_frac_built_of_measured_copy": (Bbuilt * rounds_per_s / (copy_gbs * 1e9)) if copy_gbs else None,
+                "note": "B_round = N F b (1+rho) + 8 N (1+rho) + 4 N rho + nu N (b+4+4) + 76 N + (2L-1) F T 12 (SURVEY.md 8d, b = 2); round_frac = B_round x rounds/s / 8e12",
+            },
         }
-        out["kernel_ms_per_round"] = {"hist_root": ms_root / args.steps, "lambda": ms_lam / args.steps}
+        if node:
+            nb = node["docs_per_round"] * (F_ * 2 + 8 + 4)
+            ach = nb / (node["ms_per_round"] * 1e-3) / 1e9 if node["ms_per_round"] > 0 else 0.0
+            out["roofline"]["node_histograms"] = {
+                "kernel": "rl::k_hist<false,16> (child histograms, FeatureHistogram.construct; the kernel with the largest share of a round)",
+                "ms_per_round": node["ms_per_round"], "launches_per_round": node["launches_per_round"],
+                "docs_accumulated_per_round": node["docs_per_round"], "algorithmic_bytes_per_round": nb,
+                "achieved": ach, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "frac_of_measured_gather32": (ach / gather_gbs) if gather_gbs else None,
+                "traffic_per_round": (FETCH_FACTOR_GATHER32 * pmc["node_FETCH_SIZE"] + pmc.get("node_WRITE_SIZE", 0.0)) if pmc and "node_FETCH_SIZE" in pmc else None,
+                "note": "algorithmic bytes = documents of the accumulated (smaller) children x (F*2 B bin ids + 8 B lambda + 4 B sample id); HIP events around "
+                        "every growth step's launch over %d extra rounds (empty launches of finished trees included); bound by LDS atomic throughput, not HBM (DESIGN.md 4.1)" % args.node_rounds,
+            }
+        out["kernel_ms_per_round"] = {"hist_root": ms_root / args.steps, "lambda": ms_lam / args.steps,
+                                      "hist_nodes": node["ms_per_round"] if node else None}
+    if sustained is not None:
+        out["config"]["sustained_rounds_per_s"] = sustained
+        out["config"]["sustained_over_rounds"] = args.sustain
 
     if args.cpu_rounds > 0 and world == 1:
         import oracle_ffi as O

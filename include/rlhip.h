@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define RLHIP_ABI_VERSION 2
+#define RLHIP_ABI_VERSION 3
 
 enum {
     RL_OK = 0,
@@ -137,6 +137,11 @@ int rl_set_train(rl_trainer *t, const float *X, int64_t n_docs, int32_t n_featur
 /* Ranker.setValidationSet (learning/Ranker.java:68-70); same layout, same feature columns. */
 int rl_set_validation(rl_trainer *t, const float *X, int64_t n_docs, const float *labels, const int32_t *qoff,
                       int32_t n_queries, const int32_t *qkey);
+
+/* Chunked upload for callers that cannot hold the whole row matrix in one buffer (a Java direct ByteBuffer ends at 2 GiB; MSLR-WEB30K's
+ * 3.77 M x 136 floats are 2.05 GB): pass X = NULL to rl_set_train / rl_set_validation (labels, qoff, ids as usual), then deliver the rows
+ * in consecutive blocks, first_doc ascending from 0, before rl_init.  X: row-major [n_docs][n_features] of that block. */
+int rl_set_rows(rl_trainer *t, int32_t validation, int64_t first_doc, int64_t n_docs, const float *X);
 
 int rl_init(rl_trainer *t);
 
@@ -240,6 +245,9 @@ enum {
                                    splits committed to trees, trees grown -- speculative best-first growth */
     RL_ARR_ROOT_SUM_JAVA = 17,  /* double[n_features*stride]   with RL_FLAG_JAVA_ORDER: cumulative root sums of the last round in the
                                    Java's own accumulation order (== FeatureHistogram.sum of the root, bit for bit) */
+    RL_ARR_GROW_DOCS = 18,      /* int64[4] cumulative documents: accumulated into child histograms (the smaller child of every prepared
+                                   node), partitioned, left children of committed splits (= what the Java accumulates: the rho of
+                                   SURVEY.md 8d times N), committed split nodes (nu times N) */
     RL_ARR_PHASE_CLOCKS = 16    /* int64[64][16] device wall-clock stamps (10 ns) inside the last 64 growth steps; all zero unless the
                                    library was built with -DRL_PHASE_CLOCKS (tools/phase_clocks.py) */
 };
@@ -258,6 +266,15 @@ enum { RL_KERNEL_HIST_ROOT = 0, RL_KERNEL_HIST_NODE = 1, RL_KERNEL_LAMBDA = 2, R
 /* With RL_FLAG_TIMING: accumulated HIP-event time (ms), launch count and algorithmic bytes of a kernel
  * since the last rl_reset_timing. */
 int rl_get_timing(rl_trainer *t, int32_t kernel, double *total_ms, int64_t *launches, double *alg_bytes);
+/* Switch the RL_FLAG_TIMING / RL_FLAG_TIMING_NODES bits of a live trainer (bench.py times the headline region without the 30
+ * per-step event pairs, then a few more rounds with them). */
+int rl_set_timing_flags(rl_trainer *t, int32_t flags);
+/* Memory micro-benchmarks with this library's own access patterns ("re-measure with the build's own copy kernel"),
+ * also the known byte counts that calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE (tools/calib_fetch.sh):
+ * mode 0 = copy (16 B per lane; reads + writes `bytes`), 1 = streaming read of `bytes`, 2 = streaming write, 3 = 32-byte row
+ * gathers through an ascending index list that takes one row in `stride` (the child-node histogram pattern; 32 B row + 4 B
+ * index per entry).  avg_ms = mean HIP-event time of `iters` launches, alg_bytes = algorithmic bytes of one launch. */
+int rl_debug_membench(int32_t device, int32_t mode, int64_t bytes, int32_t stride, int32_t iters, double *avg_ms, double *alg_bytes);
 int rl_reset_timing(rl_trainer *t);
 
 #ifdef __cplusplus

@@ -50,10 +50,13 @@ public class LambdaMART extends Ranker {
         super(samples, features, scorer);
     }
 
+    /** rows per rl_set_rows block: the direct buffer stays far below Integer.MAX_VALUE bytes whatever the data set's size */
+    private static final int UPLOAD_BLOCK_BYTES = 64 << 20;
+
     private void upload(final List<RankList> lists, final boolean validation, final Map<String, Integer> qids) {
         long n = 0;
         for (final RankList rl : lists) n += rl.size();
-        final FloatBuffer X = ByteBuffer.allocateDirect((int) (n * features.length * 4)).order(ByteOrder.nativeOrder()).asFloatBuffer();
+        if (n > Integer.MAX_VALUE - 4096) throw RankLibError.create("rlhip: more than 2^31 documents in one data set");
         final float[] labels = new float[(int) n];
         final int[] qoff = new int[lists.size() + 1];
         final int[] qkey = new int[lists.size()];
@@ -63,14 +66,24 @@ public class LambdaMART extends Ranker {
             Integer key = qids.get(rl.getID());                  // equal qid strings share the idealGains cache entry
             if (key == null) { key = qids.size(); qids.put(rl.getID(), key); }
             qkey[q] = key;
-            for (int j = 0; j < rl.size(); j++, k++) {
-                final DataPoint dp = rl.get(j);
-                labels[k] = dp.getLabel();
-                for (final int fid : features) X.put(dp.getFeatureValue(fid));     // NaN/missing -> 0 here, as in the reference
-            }
+            for (int j = 0; j < rl.size(); j++, k++) labels[k] = rl.get(j).getLabel();
             qoff[q + 1] = k;
         }
-        RlHipNative.setData(handle, validation, X, n, features.length, labels, qoff, validation ? null : features, qkey);
+        // labels / offsets first (X = null), then the rows in blocks through ONE reusable direct buffer (rlhip.h rl_set_rows):
+        // MSLR-WEB30K's 3.77 M x 136 floats are 2.05 GB, more than a ByteBuffer can hold
+        RlHipNative.setData(handle, validation, null, n, features.length, labels, qoff, validation ? null : features, qkey);
+        final int rowsPerBlock = Math.max(1, UPLOAD_BLOCK_BYTES / (4 * features.length));
+        final FloatBuffer X = ByteBuffer.allocateDirect(rowsPerBlock * features.length * 4).order(ByteOrder.nativeOrder()).asFloatBuffer();
+        long first = 0;
+        int inBlock = 0;
+        for (final RankList rl : lists) {
+            for (int j = 0; j < rl.size(); j++) {
+                final DataPoint dp = rl.get(j);
+                for (final int fid : features) X.put(dp.getFeatureValue(fid));     // NaN/missing -> 0 here, as in the reference
+                if (++inBlock == rowsPerBlock) { RlHipNative.setRows(handle, validation, first, inBlock, X); first += inBlock; inBlock = 0; X.clear(); }
+            }
+        }
+        if (inBlock > 0) RlHipNative.setRows(handle, validation, first, inBlock, X);
     }
 
     @Override
@@ -82,10 +95,16 @@ public class LambdaMART extends Ranker {
         handle = RlHipNative.create(nTrees, nTreeLeaves, nThreshold, minLeafSupport, nRoundToStopEarly, learningRate, metric, scorer.getK(),
                 rankerId(), device, FeatureHistogram.samplingRate, seed++);
         impacts = new double[features.length];
-        final Map<String, Integer> qids = new HashMap<>();
-        upload(samples, false, qids);
-        if (validationSamples != null) upload(validationSamples, true, qids);
-        RlHipNative.init(handle);
+        try {
+            final Map<String, Integer> qids = new HashMap<>();
+            upload(samples, false, qids);
+            if (validationSamples != null) upload(validationSamples, true, qids);
+            RlHipNative.init(handle);
+        } catch (final RuntimeException e) {      // never leak the device memory behind a failed init
+            RlHipNative.destroy(handle);
+            handle = 0;
+            throw e;
+        }
     }
 
     @Override
@@ -94,29 +113,32 @@ public class LambdaMART extends Ranker {
         logger.info(() -> "Training starts...");
         if (validationSamples != null) printLogLn(new int[] { 7, 9, 9 }, new String[] { "#iter", scorer.name() + "-T", scorer.name() + "-V" });
         else printLogLn(new int[] { 7, 9 }, new String[] { "#iter", scorer.name() + "-T" });
-        final int cap = 2 * nTreeLeaves - 1;
+        final int cap = Math.max(3, 2 * nTreeLeaves - 1);          // the root always splits once (RegressionTree.java:62-67): -leaf 1 still yields 3 nodes
         final int[] feature = new int[cap], left = new int[cap], right = new int[cap];
         final float[] threshold = new float[cap], output = new float[cap], metrics = new float[2];
-        for (int m = 0; m < nTrees; m++) {
-            printLog(new int[] { 7 }, new String[] { Integer.toString(m + 1) });
-            final int r = RlHipNative.boostRound(handle, feature, threshold, left, right, output, metrics);
-            ensemble.add(new RegressionTree(build(0, feature, threshold, left, right, output)), learningRate);
-            printLog(new int[] { 9 }, new String[] { Double.toString(SimpleMath.round(metrics[0], 4)) });
-            if (validationSamples != null) printLog(new int[] { 9 }, new String[] { Double.toString(SimpleMath.round(metrics[1], 4)) });
-            flushLog();
-            if (r < 0) break;                                       // early stop (learning/tree/LambdaMART.java:248)
+        try {
+            for (int m = 0; m < nTrees; m++) {
+                printLog(new int[] { 7 }, new String[] { Integer.toString(m + 1) });
+                final int r = RlHipNative.boostRound(handle, feature, threshold, left, right, output, metrics);
+                ensemble.add(new RegressionTree(build(0, feature, threshold, left, right, output)), learningRate);
+                printLog(new int[] { 9 }, new String[] { Double.toString(SimpleMath.round(metrics[0], 4)) });
+                if (validationSamples != null) printLog(new int[] { 9 }, new String[] { Double.toString(SimpleMath.round(metrics[1], 4)) });
+                flushLog();
+                if (r < 0) break;                                       // early stop (learning/tree/LambdaMART.java:248)
+            }
+            final double[] fin = RlHipNative.finish(handle);             // rollback + scorer.score(rank(samples))
+            while (ensemble.treeCount() > RlHipNative.numTrees(handle)) ensemble.remove(ensemble.treeCount() - 1);
+            scoreOnTrainingData = fin[0];
+            logger.info(() -> "Finished sucessfully.");
+            logger.info(() -> scorer.name() + " on training data: " + SimpleMath.round(scoreOnTrainingData, 4));
+            if (validationSamples != null) {
+                bestScoreOnValidationData = fin[1];
+                logger.info(() -> scorer.name() + " on validation data: " + SimpleMath.round(bestScoreOnValidationData, 4));
+            }
+        } finally {
+            RlHipNative.destroy(handle);
+            handle = 0;
         }
-        final double[] fin = RlHipNative.finish(handle);             // rollback + scorer.score(rank(samples))
-        while (ensemble.treeCount() > RlHipNative.numTrees(handle)) ensemble.remove(ensemble.treeCount() - 1);
-        scoreOnTrainingData = fin[0];
-        logger.info(() -> "Finished sucessfully.");
-        logger.info(() -> scorer.name() + " on training data: " + SimpleMath.round(scoreOnTrainingData, 4));
-        if (validationSamples != null) {
-            bestScoreOnValidationData = fin[1];
-            logger.info(() -> scorer.name() + " on validation data: " + SimpleMath.round(bestScoreOnValidationData, 4));
-        }
-        RlHipNative.destroy(handle);
-        handle = 0;
     }
 
     private static Split build(final int n, final int[] f, final float[] t, final int[] l, final int[] r, final float[] o) {

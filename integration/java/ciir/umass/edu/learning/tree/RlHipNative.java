@@ -12,6 +12,8 @@ final class RlHipNative {
     static native void destroy(long h);
     static native int setData(long h, boolean validation, FloatBuffer X, long nDocs, int nFeatures, float[] labels, int[] qoff,
             int[] featureIds, int[] qkey);
+    /** a block of rows after setData(.., X = null, ..): X holds nDocs * nFeatures floats from position 0 (rlhip.h rl_set_rows) */
+    static native int setRows(long h, boolean validation, long firstDoc, long nDocs, FloatBuffer X);
     static native int init(long h);
     static native int boostRound(long h, int[] feature, float[] threshold, int[] left, int[] right, float[] output, float[] metrics);
     static native double[] finish(long h);

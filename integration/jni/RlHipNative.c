@@ -44,7 +44,7 @@ JNIEXPORT void JNICALL Java_ciir_umass_edu_learning_tree_RlHipNative_destroy(JNI
 JNIEXPORT jint JNICALL Java_ciir_umass_edu_learning_tree_RlHipNative_setData(JNIEnv *env, jclass c, jlong h, jboolean validation,
         jobject X, jlong nDocs, jint nFeatures, jfloatArray labels, jintArray qoff, jintArray featureIds, jintArray qkey)
 {
-    float *x = (float *)(*env)->GetDirectBufferAddress(env, X);
+    float *x = X ? (float *)(*env)->GetDirectBufferAddress(env, X) : NULL;      /* null: the rows follow through setRows */
     jint nq = (*env)->GetArrayLength(env, qoff) - 1;
     jfloat *lab = (*env)->GetFloatArrayElements(env, labels, NULL);
     jint *qo = (*env)->GetIntArrayElements(env, qoff, NULL);
@@ -58,6 +58,14 @@ JNIEXPORT jint JNICALL Java_ciir_umass_edu_learning_tree_RlHipNative_setData(JNI
     if (fid) (*env)->ReleaseIntArrayElements(env, featureIds, fid, JNI_ABORT);
     if (qk) (*env)->ReleaseIntArrayElements(env, qkey, qk, JNI_ABORT);
     CHECK(rc);
+    return 0;
+}
+
+/* rows [firstDoc, firstDoc + nDocs) of the data set declared by setData(.., X = null, ..) */
+JNIEXPORT jint JNICALL Java_ciir_umass_edu_learning_tree_RlHipNative_setRows(JNIEnv *env, jclass c, jlong h, jboolean validation,
+        jlong firstDoc, jlong nDocs, jobject X)
+{
+    CHECK(rl_set_rows((rl_trainer *)(intptr_t)h, validation ? 1 : 0, firstDoc, nDocs, (const float *)(*env)->GetDirectBufferAddress(env, X)));
     return 0;
 }
 

@@ -37,18 +37,19 @@ class RlTree(C.Structure):
 
 RL_FLAG_FAST_LEAF, RL_FLAG_TIMING, RL_FLAG_SERIAL_CHAIN, RL_FLAG_TIMING_NODES, RL_FLAG_JAVA_ORDER = 1, 2, 4, 8, 16
 ARR = dict(LAMBDA=1, WEIGHT=2, SCORE=3, VALID_SCORE=4, NBINS=5, THRESHOLDS=6, BINS=7, ROOT_COUNT=8, ROOT_SUM=9,
-           QUANT=10, ROOT_SUM_FIXED=11, NDCG_PER_QUERY=12, CHAIN_STATS=13, CHAIN_MISS=14, GROW_STATS=15, PHASE_CLOCKS=16)
+           QUANT=10, ROOT_SUM_FIXED=11, NDCG_PER_QUERY=12, CHAIN_STATS=13, CHAIN_MISS=14, GROW_STATS=15, PHASE_CLOCKS=16,
+           ROOT_SUM_JAVA=17, GROW_DOCS=18)
 KERNEL = dict(HIST_ROOT=0, HIST_NODE=1, LAMBDA=2)
 
 # every symbol include/rlhip.h declares (tests/test_abi.py checks the .so exports all of them)
 ABI_SYMBOLS = [
     "rl_abi_version", "rl_last_error", "rl_device_count", "rl_params_default", "rl_create", "rl_destroy",
-    "rl_set_train", "rl_set_validation", "rl_init", "rl_boost_round", "rl_boost_rounds_async", "rl_sync",
+    "rl_set_train", "rl_set_validation", "rl_set_rows", "rl_init", "rl_boost_round", "rl_boost_rounds_async", "rl_sync",
     "rl_finish", "rl_num_trees", "rl_get_tree", "rl_get_round_metrics", "rl_best_validation", "rl_predict",
     "rl_model_to_text", "rl_model_from_text", "rl_model_destroy", "rl_model_num_trees", "rl_model_features",
     "rl_model_predict", "rl_model_predict_device", "rl_dist_unique_id", "rl_dist_init", "rl_dist_init_callback", "rl_bin_stride", "rl_quant_exponent", "rl_get_array", "rl_debug_exp", "rl_debug_float_chain",
     "rl_letor_parse", "rl_letor_info", "rl_letor_arrays", "rl_letor_rows", "rl_letor_destroy",
-    "rl_get_timing", "rl_reset_timing",
+    "rl_get_timing", "rl_reset_timing", "rl_set_timing_flags", "rl_debug_membench",
 ]
 
 HOST_ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32)
@@ -78,6 +79,7 @@ def lib():
     L.rl_destroy.restype = None
     L.rl_set_train.argtypes = [vp, vp, i64, i32, vp, vp, i32, vp, vp]
     L.rl_set_validation.argtypes = [vp, vp, i64, vp, vp, i32, vp]
+    L.rl_set_rows.argtypes = [vp, i32, i64, i64, vp]
     L.rl_init.argtypes = [vp]
     L.rl_boost_round.argtypes = [vp, C.POINTER(RlTree), f32p, f32p, C.POINTER(i32)]
     L.rl_boost_rounds_async.argtypes = [vp, i32]
@@ -112,6 +114,8 @@ def lib():
     L.rl_letor_destroy.restype = None
     L.rl_get_timing.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
     L.rl_reset_timing.argtypes = [vp]
+    L.rl_set_timing_flags.argtypes = [vp, i32]
+    L.rl_debug_membench.argtypes = [i32, i32, i64, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     _lib = L
     return L
 
@@ -196,6 +200,13 @@ def debug_float_chain(x, seg_start=None, device=0):
     return out, stats
 
 
+def membench(mode, nbytes, stride=1, iters=10, device=0):
+    """rl_debug_membench: (avg ms per launch, algorithmic bytes per launch); mode: 0 copy, 1 read, 2 write, 3 32-byte row gather"""
+    ms, b = C.c_double(0), C.c_double(0)
+    check(lib().rl_debug_membench(device, mode, nbytes, stride, iters, C.byref(ms), C.byref(b)))
+    return ms.value, b.value
+
+
 class Trainer:
     """Thin object wrapper over the rl_trainer handle (one GPU)."""
 
@@ -227,13 +238,21 @@ class Trainer:
         qk = None if qkey is None else np.ascontiguousarray(qkey, dtype=np.int32)
         return X, labels, qoff, qk
 
-    def set_train(self, X, labels, qoff, feature_ids=None, qkey=None):
+    def set_train(self, X, labels, qoff, feature_ids=None, qkey=None, chunk_rows=None):
+        """chunk_rows: deliver the rows through rl_set_rows in blocks of that many documents (what the JNI shim does)"""
         X, labels, qoff, qk = self._prep(X, labels, qoff, qkey)
         fid = None if feature_ids is None else np.ascontiguousarray(feature_ids, dtype=np.int32)
         self.N, self.F = X.shape
         self.Q = len(qoff) - 1
-        check(lib().rl_set_train(self.h, X.ctypes.data, self.N, self.F, labels.ctypes.data, qoff.ctypes.data, self.Q,
+        check(lib().rl_set_train(self.h, None if chunk_rows else X.ctypes.data, self.N, self.F, labels.ctypes.data, qoff.ctypes.data, self.Q,
                                  None if fid is None else fid.ctypes.data, None if qk is None else qk.ctypes.data))
+        if chunk_rows:
+            self.set_rows(X, False, chunk_rows)
+
+    def set_rows(self, X, validation, chunk_rows):
+        for a in range(0, X.shape[0], chunk_rows):
+            blk = np.ascontiguousarray(X[a:a + chunk_rows])
+            check(lib().rl_set_rows(self.h, 1 if validation else 0, a, blk.shape[0], blk.ctypes.data))
 
     def set_validation(self, X, labels, qoff, qkey=None):
         X, labels, qoff, qk = self._prep(X, labels, qoff, qkey)
@@ -352,9 +371,9 @@ class Trainer:
             "LAMBDA": ((self.N,), np.float64), "WEIGHT": ((self.N,), np.float64), "SCORE": ((self.N,), np.float64),
             "VALID_SCORE": ((self.Nv,), np.float64), "NBINS": ((self.F,), np.int32),
             "THRESHOLDS": ((self.F, TS), np.float32), "BINS": ((self.F, self.N), np.uint16),
-            "ROOT_COUNT": ((self.F, TS), np.int32), "ROOT_SUM": ((self.F, TS), np.float64),
+            "ROOT_COUNT": ((self.F, TS), np.int32), "ROOT_SUM": ((self.F, TS), np.float64), "ROOT_SUM_JAVA": ((self.F, TS), np.float64),
             "QUANT": ((self.N,), np.int64), "ROOT_SUM_FIXED": ((self.F, TS, 2), np.int64),
-            "NDCG_PER_QUERY": ((self.Q,), np.float64), "CHAIN_STATS": ((6,), np.int32), "GROW_STATS": ((4,), np.int32), "PHASE_CLOCKS": ((64, 16), np.int64), "CHAIN_MISS": ((2, 2 * self.p.n_leaves), np.int32),
+            "NDCG_PER_QUERY": ((self.Q,), np.float64), "CHAIN_STATS": ((6,), np.int32), "GROW_STATS": ((4,), np.int32), "GROW_DOCS": ((4,), np.int64), "PHASE_CLOCKS": ((64, 16), np.int64), "CHAIN_MISS": ((2, 2 * self.p.n_leaves), np.int32),
         }
         shape, dt = shapes[name]
         out = np.zeros(shape, dt)
@@ -368,6 +387,9 @@ class Trainer:
 
     def reset_timing(self):
         check(lib().rl_reset_timing(self.h))
+
+    def set_timing_flags(self, flags):
+        check(lib().rl_set_timing_flags(self.h, flags))
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:

@@ -110,6 +110,10 @@ struct Ctx {
     // static per data set
     const uint16_t *bins;   // [F][Npad]  feature-major: single-column scans (partition)
     const uint16_t *gbins;  // [numFG][Npad][kHistFG]  group-major: one 32-byte row per document and group (histograms)
+    const uint16_t *dbins;  // [Npad][numFG][kHistFG]  document-major: ALL groups of a document adjacent (numFG x 32 bytes).  A sparse node's
+                            // sample list touches one 128-byte memory line per (document, group) in gbins -- 4 x the bytes it uses -- but only
+                            // the document's own ~numFG/4 lines here; the feature-group blocks of one chunk run on one XCD and share them in L2
+    int32_t dm_root, dm_div;   // document-major rows for the root pass (0 / 1); for a node of cnt samples when cnt * dm_div <= N (0 = never, 1 = every child)
     int32_t sub;            // features of a group handled per histogram block (kHistFG unless the threshold table is huge)
     const int32_t *mode;    // [F] most populated bin of every feature: never accumulated, rebuilt as total - others
     const float *thr;       // [F][TS]
@@ -140,6 +144,9 @@ struct Ctx {
     long long *tile_sq;                                                // [nTiles] lambda^2 partial of each partition tile's left members
     int32_t *leaf_node, *leaf_start;                                   // [MAXN], [MAXN+1]
     int32_t *grow_stats;                                               // [4] cumulative: growth steps, nodes prepared, splits committed, trees
+    unsigned long long *grow_docs;                                     // [4] cumulative documents: accumulated into child histograms (the smaller child of every
+                                                                       // PREPARED node), partitioned (prepared nodes), left children of COMMITTED splits (what the
+                                                                       // Java accumulates: rho of SURVEY.md 8d), committed split nodes (nu)
     float *round_metric;                                               // [n_trees][2]
     // host-visible (pinned, fine-grained) growth progress: tree_seq << 32 | select_step calls in the tree << 1 | done.
     // A HINT only: the host uses it to stop enqueuing growth steps of a finished tree (extra steps are no-ops).

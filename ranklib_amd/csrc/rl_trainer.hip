@@ -19,6 +19,8 @@
 #include "rl_kernels_init.inc"
 #include "rl_chain.inc"
 #include "rl_kernels_round.inc"
+#include "rl_java_order.inc"
+#include "rl_membench.inc"
 #include "rl_dist.inc"
 #include "rl_model.h"
 
@@ -48,6 +50,7 @@ struct DataSet {
     int64_t N = 0; int32_t Q = 0;
     std::vector<float> labels; std::vector<int32_t> qoff, qkey; bool has_key = false;
     float *d_X = nullptr;          // row-major rows [N][F]
+    int64_t rows_next = -1;        // chunked upload (rl_set_rows): next row expected; -1 = the rows came with rl_set_train / rl_set_validation
     float *d_labels = nullptr; int32_t *d_qoff = nullptr; double *d_ideal0 = nullptr, *d_ideal1 = nullptr;
     double *d_scores = nullptr, *d_ndcg = nullptr;
     double *d_ss = nullptr; float *d_sl = nullptr; int32_t *d_srel = nullptr, *d_sidx = nullptr, *d_docq = nullptr;   // ranked order (training set only)
@@ -129,7 +132,7 @@ static double ideal_dcg(const float *labels, int n, int topk, const std::vector<
 
 static int validate_dataset(const float *X, int64_t n, int32_t F, const float *labels, const int32_t *qoff, int32_t Q)
 {
-    if (!X || !labels || !qoff) return fail(RL_ERR_INVALID, "null data pointer");
+    if (!labels || !qoff) return fail(RL_ERR_INVALID, "null data pointer");       // X == NULL: the rows follow through rl_set_rows
     if (n <= 0 || Q <= 0 || F <= 0) return fail(RL_ERR_INVALID, "There are no training samples / features");
     if (n >= (int64_t)2147483647 - 4096) return fail(RL_ERR_UNSUPPORTED, "more than 2^31 documents per GPU");
     if (qoff[0] != 0 || (int64_t)qoff[Q] != n) return fail(RL_ERR_INVALID, "qoff must start at 0 and end at n_docs");
@@ -155,7 +158,8 @@ static int load_dataset(rl_trainer *t, DataSet &d, const float *X, int64_t n, co
     if (d.maxq > kLambdaBlockCap)
         return fail(RL_ERR_UNSUPPORTED, "a ranked list with more than " + std::to_string(kLambdaBlockCap) + " documents");
     RL_HIP(t->pool.alloc(&d.d_X, (size_t)n * t->F));
-    RL_HIP(hipMemcpy(d.d_X, X, (size_t)n * t->F * sizeof(float), hipMemcpyHostToDevice));
+    if (X) { RL_HIP(hipMemcpy(d.d_X, X, (size_t)n * t->F * sizeof(float), hipMemcpyHostToDevice)); d.rows_next = -1; }
+    else d.rows_next = 0;
     return RL_OK;
 }
 
@@ -453,13 +457,18 @@ static int enqueue_round(rl_trainer *t)
     }
     // the last block of k_hist_finish runs the growth bookkeeping (select_step); node records live in LDS when they fit
     const int nodes_in_lds = (select_lds_bytes(c.L, c.NC, true, c.F, c.fs_size < c.F) <= 60 * 1024) ? 1 : 0;
-    const size_t fin_lds = std::max((size_t)c.TS * 20, select_lds_bytes(c.L, c.NC, nodes_in_lds != 0, c.F, c.fs_size < c.F));
+    const size_t fin_lds = std::max((size_t)c.TS * (c.java ? 28 : 20) + 8, select_lds_bytes(c.L, c.NC, nodes_in_lds != 0, c.F, c.fs_size < c.F));
+    const int jbg = (c.TS + 63) / 64;        // RL_FLAG_JAVA_ORDER: 64-bin groups of k_jhist (+ 1 block for the node totals)
     if (fin_lds > 128 * 1024) return fail(RL_ERR_UNSUPPORTED, "too many features / leaves for the growth bookkeeping in LDS (feature sampling needs 64 bytes per feature)");
     if (t->dist) {
         hipLaunchKernelGGL(k_hist_reduce, dim3(c.F), dim3(kFinThreads), red_lds, s, c, 1);
         int rcd = t->dist->allreduce(c.dist_buf, (size_t)c.F * c.TS * c.limb_words + 4, DT_I64, OP_SUM, s);
         if (rcd) return rcd;
         hipLaunchKernelGGL((k_hist_finish<true, true>), dim3(c.F), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
+    } else if (c.java) {
+        hipLaunchKernelGGL(k_jgather, dim3((c.N + kPartTile - 1) / kPartTile), dim3(kThreads), 0, s, c, 1);
+        hipLaunchKernelGGL(k_jhist, dim3(c.n_live, jbg + 2, 1), dim3(64), 0, s, c, 1, jbg);
+        hipLaunchKernelGGL((k_hist_finish<true, false, true>), dim3(c.n_live), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
     } else hipLaunchKernelGGL((k_hist_finish<true, false>), dim3(c.n_live), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
     // Growth steps: each prepares up to kSpec queue nodes and commits as many splits as the fit loop allows; L-1 steps
     // always suffice (every step commits at least the head of the queue); finished trees make the rest no-ops.
@@ -523,6 +532,10 @@ static int enqueue_round(rl_trainer *t)
                 RL_HIP(hipMemcpy(&done, &c.st->done, sizeof(done), hipMemcpyDeviceToHost));
                 if (done) break;
             }
+        } else if (c.java) {
+            hipLaunchKernelGGL(k_jgather, dim3(c.nTiles), dim3(kThreads), 0, s, c, 0);
+            hipLaunchKernelGGL(k_jhist, dim3(c.n_live, jbg + 2, kSpec), dim3(64), 0, s, c, 0, jbg);
+            hipLaunchKernelGGL((k_hist_finish<false, false, true>), dim3(c.n_live, kSpec), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
         } else hipLaunchKernelGGL((k_hist_finish<false, false>), dim3(c.n_live, kSpec), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
     }
     hipLaunchKernelGGL(k_leaf_table, dim3(1), dim3(kThreads), 0, s, c, t->leaf_chain, t->d_seg_buf);
@@ -738,6 +751,8 @@ int rl_create(const rl_params *p, rl_trainer **out)
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     RL_HIP(hipFuncSetAttribute((const void *)k_rank_block, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaBlockCap * 12));
     RL_HIP(hipFuncSetAttribute((const void *)k_lambda_tiny, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaTinyGroups * lambda_tiny_group_bytes(kLambdaFusedMaxK)));
     RL_HIP(hipFuncSetAttribute((const void *)k_lambda_fused<256>, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaFusedMaxK * (256 + 8) * 16 + 2048));
@@ -799,11 +814,28 @@ int rl_set_validation(rl_trainer *t, const float *X, int64_t n_docs, const float
     return RL_OK;
 }
 
+int rl_set_rows(rl_trainer *t, int32_t validation, int64_t first_doc, int64_t n_docs, const float *X)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    if (t->inited) return fail(RL_ERR_STATE, "rows must be delivered before rl_init");
+    if (validation ? !t->has_valid : !t->has_train) return fail(RL_ERR_STATE, "rl_set_rows before rl_set_train / rl_set_validation");
+    DataSet &d = validation ? t->va : t->tr;
+    if (d.rows_next < 0) return fail(RL_ERR_STATE, "the rows of this data set were already given to rl_set_train / rl_set_validation");
+    if (!X || n_docs <= 0) return fail(RL_ERR_INVALID, "bad argument");
+    if (first_doc != d.rows_next || first_doc + n_docs > d.N) return fail(RL_ERR_INVALID, "row blocks must be consecutive and stay inside the data set");
+    RL_HIP(hipSetDevice(t->p.device));
+    RL_HIP(hipMemcpy(d.d_X + (size_t)first_doc * t->F, X, (size_t)n_docs * t->F * sizeof(float), hipMemcpyHostToDevice));
+    d.rows_next += n_docs;
+    return RL_OK;
+}
+
 int rl_init(rl_trainer *t)
 {
     if (check_trainer(t)) return RL_ERR_INVALID;
     if (!t->has_train) return fail(RL_ERR_STATE, "no training set");
     if (t->inited) return fail(RL_ERR_STATE, "rl_init called twice");
+    if ((t->tr.rows_next >= 0 && t->tr.rows_next != t->tr.N) || (t->has_valid && t->va.rows_next >= 0 && t->va.rows_next != t->va.N))
+        return fail(RL_ERR_STATE, "rl_set_rows has not delivered every row yet");
     RL_HIP(hipSetDevice(t->p.device));
     RL_HIP(hipDeviceSynchronize());      // uploads of rl_set_* went through the null stream; t->stream is non-blocking
     Ctx &c = t->ctx;
@@ -916,9 +948,27 @@ int rl_init(rl_trainer *t)
     RL_HIP(t->pool.alloc(&c.cum_lo, (size_t)c.NC * F * TS));
     RL_HIP(t->pool.alloc(&c.cum_cnt, (size_t)c.NC * F * TS));
     RL_HIP(hipMemsetAsync(c.cum_cnt, 0, (size_t)F * TS * sizeof(int32_t), s));
+    c.java = (t->p.flags & RL_FLAG_JAVA_ORDER) ? 1 : 0;
+    if (c.java) {
+        if (t->dist) return fail(RL_ERR_UNSUPPORTED, "RL_FLAG_JAVA_ORDER with multi-GPU training: the Java's summation order is a single sequence over all documents");
+        RL_HIP(t->pool.alloc(&c.jl, (size_t)Npad)); RL_HIP(t->pool.alloc(&c.jb, (size_t)F * Npad));
+        RL_HIP(t->pool.alloc(&c.jbin, (size_t)kSpec * F * TS)); RL_HIP(t->pool.alloc(&c.jtot, (size_t)kSpec * 2));
+        RL_HIP(t->pool.alloc(&c.jcum, (size_t)c.NC * F * TS));
+        RL_HIP(hipMemsetAsync(c.jcum, 0, (size_t)c.NC * F * TS * sizeof(double), s));
+        RL_HIP(hipMemsetAsync(c.jbin, 0, (size_t)kSpec * F * TS * sizeof(double), s));
+    }
     hipLaunchKernelGGL(k_binning, dim3(F, slices), dim3(kThreads), (size_t)TS * 8, s, (const float *)Xt, N, Npad, TS, (const float *)d_thr,
                        (const int32_t *)d_nthr, d_bins, d_gbins, c.cum_cnt);
     if (t->dist) { int rcd = t->dist->allreduce(c.cum_cnt, (size_t)F * TS, DT_I32, OP_SUM, s); if (rcd) return rcd; }
+    {
+        uint16_t *d_dbins = nullptr;
+        RL_HIP(t->pool.alloc(&d_dbins, (size_t)c.numFG * Npad * kHistFG));
+        hipLaunchKernelGGL(k_docmajor, dim3(4096), dim3(kThreads), 0, s, (const uint16_t *)d_gbins, d_dbins, Npad, c.numFG);
+        c.dbins = d_dbins;
+        c.dm_root = 0; c.dm_div = 1;      // measured at c2 (profiles/r02d_dm_sweep.txt): every child pass gains, the root pass loses
+        if (const char *e = getenv("RLHIP_DM_ROOT")) c.dm_root = atoi(e) ? 1 : 0;      // tuning knobs (tools/), not API
+        if (const char *e = getenv("RLHIP_DM_DIV")) c.dm_div = std::max(0, atoi(e));
+    }
     int32_t *d_mode = nullptr;
     RL_HIP(t->pool.alloc(&d_mode, (size_t)F));
     c.mode = d_mode;
@@ -1016,6 +1066,7 @@ int rl_init(rl_trainer *t)
     RL_HIP(t->pool.alloc(&c.tile_cnt, (size_t)c.nTiles)); RL_HIP(t->pool.alloc(&c.tile_sq, (size_t)c.nTiles));
     RL_HIP(t->pool.alloc(&c.tile_desc, (size_t)c.nTiles)); RL_HIP(hipMemset(c.tile_desc, 0, (size_t)c.nTiles * 8));
     RL_HIP(t->pool.alloc(&c.grow_stats, (size_t)4)); RL_HIP(hipMemset(c.grow_stats, 0, 16));
+    RL_HIP(t->pool.alloc(&c.grow_docs, (size_t)4)); RL_HIP(hipMemset(c.grow_docs, 0, 32));
     RL_HIP(t->pool.alloc(&c.clk, (size_t)64 * 16)); RL_HIP(hipMemset(c.clk, 0, 64 * 16 * sizeof(long long)));
     RL_HIP(t->pool.alloc(&c.leaf_node, (size_t)c.MAXN + 1)); RL_HIP(t->pool.alloc(&c.leaf_start, (size_t)c.MAXN + 2));
     RL_HIP(t->pool.alloc(&c.round_metric, (size_t)2 * t->p.n_trees));
@@ -1358,6 +1409,7 @@ int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes)
     case RL_ARR_QUANT: src = c.q; bytes = (size_t)c.N * 8; break;
     case RL_ARR_NDCG_PER_QUERY: src = c.ndcg_q; bytes = (size_t)c.Q * 8; break;
     case RL_ARR_GROW_STATS: src = c.grow_stats; bytes = 16; break;
+    case RL_ARR_GROW_DOCS: src = c.grow_docs; bytes = 32; break;
     case RL_ARR_PHASE_CLOCKS: src = c.clk; bytes = 64 * 16 * sizeof(long long); break;
     case RL_ARR_CHAIN_STATS: {
         if (cap_bytes < 24) return fail(RL_ERR_INVALID, "output buffer too small");
@@ -1391,6 +1443,14 @@ int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes)
         RL_HIP(hipStreamSynchronize(t->stream));
         RL_HIP(hipMemcpy(out, d, bytes, hipMemcpyDeviceToHost));
         (void)hipFree(d);
+        return RL_OK;
+    }
+    case RL_ARR_ROOT_SUM_JAVA: {
+        if (!c.java) return fail(RL_ERR_STATE, "RL_ARR_ROOT_SUM_JAVA needs RL_FLAG_JAVA_ORDER");
+        bytes = (size_t)c.F * c.TS * 8;
+        if ((int64_t)bytes > cap_bytes) return fail(RL_ERR_INVALID, "output buffer too small");
+        RL_HIP(hipStreamSynchronize(t->stream));
+        RL_HIP(hipMemcpy(out, c.jcum, bytes, hipMemcpyDeviceToHost));       // node 0 = the root
         return RL_OK;
     }
     default: return fail(RL_ERR_INVALID, "unknown array id");
@@ -1450,6 +1510,57 @@ int rl_debug_float_chain(int32_t device, const double *x, int64_t n, const int64
     RL_HIP(hipStreamSynchronize(t->stream));
     RL_HIP(hipMemcpy(out, b.result, (size_t)n_seg * sizeof(float), hipMemcpyDeviceToHost));
     if (stats) RL_HIP(hipMemcpy(stats, b.stats, 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return RL_OK;
+}
+
+int rl_debug_membench(int32_t device, int32_t mode, int64_t bytes, int32_t stride, int32_t iters, double *avg_ms, double *alg_bytes)
+{
+    if (!avg_ms || bytes < 4096 || iters < 1 || mode < 0 || mode > 3 || (mode == 3 && stride < 1)) return fail(RL_ERR_INVALID, "bad argument");
+    RL_HIP(hipSetDevice(device));
+    const size_t n16 = (size_t)bytes / 16;
+    uint4 *a = nullptr, *b = nullptr; int *idx = nullptr; unsigned *sink = nullptr;
+    struct Guard { void **p[4]; ~Guard() { for (auto q : p) if (*q) (void)hipFree(*q); } } guard{{(void **)&a, (void **)&b, (void **)&idx, (void **)&sink}};
+    hipStream_t s = nullptr;
+    RL_HIP(hipMalloc((void **)&a, n16 * 16));
+    RL_HIP(hipMemset(a, 1, n16 * 16));
+    if (mode == 0) { RL_HIP(hipMalloc((void **)&b, n16 * 16)); RL_HIP(hipMemset(b, 0, n16 * 16)); }
+    const unsigned grid = 256 * 16;
+    RL_HIP(hipMalloc((void **)&sink, grid * sizeof(unsigned)));
+    size_t n_idx = 0;
+    if (mode == 3) {
+        n_idx = (n16 / 2) / (size_t)stride;
+        if (n_idx == 0) return fail(RL_ERR_INVALID, "buffer too small for this stride");
+        RL_HIP(hipMalloc((void **)&idx, n_idx * sizeof(int)));
+        hipLaunchKernelGGL(k_mb_fill_idx, dim3(1024), dim3(kThreads), 0, s, idx, n_idx, stride, stride);
+    }
+    hipEvent_t e0, e1;
+    RL_HIP(hipEventCreate(&e0)); RL_HIP(hipEventCreate(&e1));
+    double bytes_per = 0;
+    for (int it = -1; it < iters; it++) {       // it == -1: warm-up
+        if (it == 0) RL_HIP(hipEventRecord(e0, s));
+        switch (mode) {
+        case 0: hipLaunchKernelGGL(k_mb_copy, dim3(grid), dim3(kThreads), 0, s, (const uint4 *)a, b, n16); bytes_per = 2.0 * n16 * 16; break;
+        case 1: hipLaunchKernelGGL(k_mb_read, dim3(grid), dim3(kThreads), 0, s, (const uint4 *)a, n16, sink); bytes_per = 1.0 * n16 * 16; break;
+        case 2: hipLaunchKernelGGL(k_mb_write, dim3(grid), dim3(kThreads), 0, s, a, n16); bytes_per = 1.0 * n16 * 16; break;
+        default: hipLaunchKernelGGL(k_mb_gather32, dim3(grid), dim3(kThreads), 0, s, (const uint4 *)a, (const int *)idx, n_idx, sink); bytes_per = 36.0 * n_idx; break;
+        }
+    }
+    RL_HIP(hipEventRecord(e1, s));
+    RL_HIP(hipEventSynchronize(e1));
+    RL_HIP(hipGetLastError());
+    float ms = 0;
+    RL_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_ms = (double)ms / iters;
+    if (alg_bytes) *alg_bytes = bytes_per;
+    return RL_OK;
+}
+
+int rl_set_timing_flags(rl_trainer *t, int32_t flags)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    const int32_t mask = RL_FLAG_TIMING | RL_FLAG_TIMING_NODES;
+    t->p.flags = (t->p.flags & ~mask) | (flags & mask);
     return RL_OK;
 }
 

@@ -73,6 +73,34 @@ def run(name):
     print(name, "rounds", rounds, "kept", int(out["trees_kept"]), "final", float(out["final_train"]))
 
 
+def write_letor(name):
+    """the fixture's INPUTS as LETOR text (tests/golden/letor/): what integration/java/GoldenDump.java feeds to RankLib's own classes
+    on a machine with a JDK, so that tests/golden/java/<name>.txt can hold reference-OBSERVED vectors (tests/test_java_golden.py).
+    Values are the shortest decimal strings that round-trip the float32 (Float.parseFloat gives the same bits back)."""
+    z = np.load(os.path.join(HERE, name + ".npz"), allow_pickle=True)
+    os.makedirs(os.path.join(HERE, "letor"), exist_ok=True)
+
+    def dump(path, X, lab, qoff, qprefix=""):
+        # validation lists get qids of their own ("v1", ..): NDCGScorer caches ideal DCGs per qid STRING (metric/NDCGScorer.java:114-122),
+        # and the fixtures were generated with all keys distinct
+        with open(path, "w") as f:
+            for q in range(len(qoff) - 1):
+                for i in range(int(qoff[q]), int(qoff[q + 1])):
+                    f.write("%s qid:%s%d %s\n" % (np.format_float_positional(np.float32(lab[i]), unique=True, trim="0"), qprefix, q + 1,
+                                                " ".join("%d:%s" % (j + 1, np.format_float_positional(np.float32(X[i, j]), unique=True, trim="0")) for j in range(X.shape[1]))))
+    dump(os.path.join(HERE, "letor", name + ".train.txt"), z["X"], z["labels"], z["qoff"])
+    if "Xv" in z:
+        dump(os.path.join(HERE, "letor", name + ".valid.txt"), z["Xv"], z["labels_v"], z["qoff_v"], "v")
+    p = dict((k, v) for k, v in z["params"])
+    with open(os.path.join(HERE, "letor", name + ".params.txt"), "w") as f:      # key=value lines GoldenDump reads
+        f.write("".join("%s=%s\n" % (k, p[k]) for k in sorted(p)))
+
+
 if __name__ == "__main__":
-    for n in (sys.argv[1:] or CASES):
-        run(n)
+    if sys.argv[1:2] == ["--letor-only"]:
+        for n in (sys.argv[2:] or CASES):
+            write_letor(n)
+    else:
+        for n in (sys.argv[1:] or CASES):
+            run(n)
+            write_letor(n)

@@ -604,3 +604,24 @@ def test_fuzz_of_small_configurations_has_no_unexplained_mismatch():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "300", "2024"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "300 cases: 0 mismatches" in r.stdout, r.stdout[-500:]
+
+
+def test_chunked_row_upload_equals_one_shot():
+    """rl_set_train(X = NULL) + rl_set_rows in blocks (the JNI shim's path for matrices beyond a 2 GiB direct buffer) == one upload"""
+    X, lab, qoff = make(5000, 9, "ns", 21)
+    a = N.Trainer(n_trees=3, n_leaves=7); a.set_train(X, lab, qoff); a.init()
+    b = N.Trainer(n_trees=3, n_leaves=7); b.set_train(X, lab, qoff, chunk_rows=1237); b.init()
+    for _ in range(3):
+        ta, ma, _, _ = a.boost_round()
+        tb, mb, _, _ = b.boost_round()
+        assert ma == mb
+        for k in ("feature", "threshold", "left", "right", "output", "count"):
+            assert np.array_equal(ta.trimmed()[k], tb.trimmed()[k])
+    lib = N.lib()
+    d = N.Trainer(n_trees=1, n_leaves=3)
+    Xc, labc, qoffc = np.ascontiguousarray(X, np.float32), np.ascontiguousarray(lab, np.float32), np.ascontiguousarray(qoff, np.int32)
+    N.check(lib.rl_set_train(d.h, None, Xc.shape[0], Xc.shape[1], labc.ctypes.data, qoffc.ctypes.data, len(qoffc) - 1, None, None))
+    with pytest.raises(N.RankLibError):
+        N.check(lib.rl_init(d.h))                      # rows missing
+    with pytest.raises(N.RankLibError):
+        N.check(lib.rl_set_rows(d.h, 0, 10, 5, Xc.ctypes.data))      # not consecutive

@@ -100,6 +100,7 @@ def classify(to, tg, X, lam, sampling):
     return real[0]
 
 
+JAVA = bool(os.environ.get("FUZZ_JAVA"))      # RL_FLAG_JAVA_ORDER: trees must be IDENTICAL to the oracle's (no tie may be resolved differently)
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1          # multiplies the number of lists (bigger data: several chunks / tiles per node)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -148,7 +149,8 @@ for case in range(n_cases):
         o = O.Oracle(X, lab, qoff, n_trees=rounds, n_leaves=leaves, lr=lr, n_threshold=tc, mls=mls, k=k, ranker=str(ranker), metric=str(metric),
                      n_threads=3, frate=frate, seed=seed, early_stop=estop)
         g = N.Trainer(n_trees=rounds, n_leaves=leaves, learning_rate=lr, n_threshold=tc, min_leaf_support=mls, metric_k=k, metric=str(metric),
-                      ranker=str(ranker), feature_sampling_rate=frate, seed=seed, early_stop_rounds=estop)
+                      ranker=str(ranker), feature_sampling_rate=frate, seed=seed, early_stop_rounds=estop,
+                      flags=N.RL_FLAG_JAVA_ORDER if JAVA else 0)
         g.set_train(X, lab, qoff)
         if with_valid:
             o.set_validation(Xv, labv, vqoff); g.set_validation(Xv, labv, vqoff)
@@ -167,8 +169,12 @@ for case in range(n_cases):
                 break
             assert np.array_equal(g.array("LAMBDA"), lam), "lambda, round %d" % m
             try:
-                assert_equivalent(to, tg, X, ctx="round %d" % m)
+                nt = assert_equivalent(to, tg, X, ctx="round %d" % m)
+                if JAVA:
+                    assert nt == 0, "RL_FLAG_JAVA_ORDER: %d splits store another (feature, threshold) than the oracle's, round %d" % (nt, m)
             except AssertionError:
+                if JAVA:
+                    raise
                 why = classify(to, tg, X, lam, frate < 1.0)
                 if why:
                     ties += 1
