@@ -122,6 +122,10 @@ const char *rl_last_error(void);
 int         rl_device_count(int32_t *n);
 void        rl_params_default(rl_params *p);              /* the defaults of LambdaMART.java:37-42 */
 
+/* ERRScorer.MAX (metric/ERRScorer.java:25), the divisor of ERR's relevance grades R = (2^label - 1) / MAX; `-gmax g` sets it to 2^g
+ * (eval/Evaluator.java:241-242).  A process-wide static in the reference, and here: trainers created afterwards use it.  Default 16. */
+int  rl_set_err_max(double max_gain);
+
 /* ---- trainer ----------------------------------------------------------------------------- */
 int  rl_create(const rl_params *p, rl_trainer **out);
 void rl_destroy(rl_trainer *t);

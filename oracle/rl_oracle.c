@@ -428,7 +428,9 @@ static void ap_swap_change(const float *lab, int32_t n, double *changes)
     free(relCount);
 }
 
-static double err_R(int32_t rel) { return ((1 << rel) - 1) / 16.0; }          /* ERRScorer.java:26,71-73 (MAX = 16) */
+static double g_err_max = 16.0;                                                   /* ERRScorer.MAX (static, :25); -gmax sets 2^gmax */
+void ro_set_err_max(double m) { g_err_max = m; }
+static double err_R(int32_t rel) { return ((1 << rel) - 1) / g_err_max; }        /* ERRScorer.java:71-73 */
 
 /* ERRScorer.swapChange (metric/ERRScorer.java:76-115): labels, R and np are only filled for the top `size`
  * positions (the rest stay 0), and np is the running product as written (p *= np[i]). */

@@ -45,6 +45,7 @@ typedef struct {
 /* The feature draw of one split attempt.  `node_hash`: ro_root_hash(seed, tree) at the root, ro_child_hash(parent, side) below.
  * out_order[0..size) = the drawn feature INDICES in draw order (the scan visits them in this order, so the first drawn wins a tie,
  * FeatureHistogram.java:289-309): the features sorted by (ro_feature_key(node_hash, f), f), first `size`. */
+void ro_set_err_max(double max_gain);     /* ERRScorer.MAX (metric/ERRScorer.java:25): process-wide, default 16 */
 uint64_t ro_root_hash(uint64_t seed, int32_t tree);
 uint64_t ro_child_hash(uint64_t parent, int32_t side /* 0 = left, 1 = right */);
 uint64_t ro_feature_key(uint64_t node_hash, int32_t f);

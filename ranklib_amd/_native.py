@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     "rl_model_to_text", "rl_model_from_text", "rl_model_destroy", "rl_model_num_trees", "rl_model_features",
     "rl_model_predict", "rl_model_predict_device", "rl_dist_unique_id", "rl_dist_init", "rl_dist_init_callback", "rl_bin_stride", "rl_quant_exponent", "rl_get_array", "rl_debug_exp", "rl_debug_float_chain",
     "rl_letor_parse", "rl_letor_info", "rl_letor_arrays", "rl_letor_rows", "rl_letor_destroy",
-    "rl_get_timing", "rl_reset_timing", "rl_set_timing_flags", "rl_debug_membench",
+    "rl_get_timing", "rl_reset_timing", "rl_set_timing_flags", "rl_debug_membench", "rl_set_err_max",
 ]
 
 HOST_ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32)
@@ -114,6 +114,7 @@ def lib():
     L.rl_letor_destroy.restype = None
     L.rl_get_timing.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
     L.rl_reset_timing.argtypes = [vp]
+    L.rl_set_err_max.argtypes = [C.c_double]
     L.rl_set_timing_flags.argtypes = [vp, i32]
     L.rl_debug_membench.argtypes = [i32, i32, i64, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     _lib = L
@@ -198,6 +199,11 @@ def debug_float_chain(x, seg_start=None, device=0):
     stats = np.zeros(4, np.int32)
     check(lib().rl_debug_float_chain(device, x.ctypes.data, len(x), seg.ctypes.data, len(seg) - 1, out.ctypes.data, stats.ctypes.data))
     return out, stats
+
+
+def set_err_max(max_gain):
+    """ERRScorer.MAX for trainers created afterwards (rl_set_err_max)"""
+    check(lib().rl_set_err_max(float(max_gain)))
 
 
 def membench(mode, nbytes, stride=1, iters=10, device=0):

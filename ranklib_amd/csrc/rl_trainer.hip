@@ -27,6 +27,7 @@
 namespace rl {
 
 static thread_local std::string g_err;
+static double g_err_max = 16.0;      // ERRScorer.MAX: a process-wide static in the reference as well (metric/ERRScorer.java:25)
 void set_error(const std::string &msg) { g_err = msg; }
 int fail(int code, const std::string &msg) { g_err = msg; return code; }
 
@@ -81,6 +82,7 @@ struct rl_trainer {
     DevPool pool;
     Ctx ctx;
     EnsTree ens;
+    double err_max = 16.0;      // ERRScorer.MAX when the trainer was created (rl_set_err_max)
     int32_t round = 0;          // rounds enqueued so far
     // growth progress reported by the device (Ctx::progress): the host keeps at most `step_ahead` growth steps in flight and
     // stops enqueuing steps of a finished tree; 0 = enqueue all L-1 steps blindly
@@ -360,7 +362,7 @@ static int launch_rank(rl_trainer *t, DataSet &d, const double *scores, double *
 {
     RankArgs a{scores, d.d_labels, d.d_qoff, d.d_ideal1, t->ctx.disc,
                ranked ? d.d_ss : nullptr, ranked ? d.d_sl : nullptr, ranked ? d.d_srel : nullptr, ranked ? d.d_sidx : nullptr,
-               out, t->p.metric_k, t->p.metric, ranked ? d.d_aux_i : nullptr, ranked ? d.d_aux_a : nullptr, ranked ? d.d_aux_b : nullptr};
+               out, t->p.metric_k, t->p.metric, ranked ? d.d_aux_i : nullptr, ranked ? d.d_aux_a : nullptr, ranked ? d.d_aux_b : nullptr, t->err_max};
     if (d.n_tiny > 0)
         hipLaunchKernelGGL(k_rank_tiny, dim3((d.n_tiny + kRankTinyGroups - 1) / kRankTinyGroups), dim3(kRankTinyDocs * kRankTinyGroups), 0, t->stream, a,
                            (const int *)d.d_qtiny, d.n_tiny);
@@ -701,6 +703,13 @@ void rl_params_default(rl_params *p)
     p->feature_sampling_rate = 1.0f; p->seed = 0;
 }
 
+int rl_set_err_max(double max_gain)
+{
+    if (!(max_gain > 0.0) || !std::isfinite(max_gain)) return fail(RL_ERR_INVALID, "ERRScorer.MAX must be positive and finite");
+    g_err_max = max_gain;
+    return RL_OK;
+}
+
 int rl_create(const rl_params *p, rl_trainer **out)
 {
     if (!p || !out) return fail(RL_ERR_INVALID, "null argument");
@@ -729,6 +738,7 @@ int rl_create(const rl_params *p, rl_trainer **out)
         return fail(RL_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", librlhip is built for gfx950 only");
     std::unique_ptr<rl_trainer> t(new rl_trainer());
     t->p = *p;
+    t->err_max = g_err_max;
     memset(&t->ctx, 0, sizeof(t->ctx));
     memset(&t->ens, 0, sizeof(t->ens));
     RL_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));

@@ -5,13 +5,14 @@
     python -m ranklib_amd.evaluator -load model.txt -rank f -score out.txt
 """
 import logging
+import math
 import sys
 
 from ._native import RankLibError
 from .features import FeatureManager
-from .learning import (DataPoint, FeatureHistogram, LambdaMART, RankerFactory, RankerTrainer, RankerType, RFRanker, java_round,
+from .learning import (DataPoint, FeatureHistogram, LambdaMART, RankerFactory, RankerTrainer, RankerType, RFRanker, java_double_str, java_round,
                        stable_desc_order)
-from .metric import MetricScorerFactory
+from .metric import ERRScorer, MetricScorerFactory
 
 logger = logging.getLogger("ranklib_amd")
 
@@ -112,7 +113,7 @@ class Evaluator:
         with open(outputFile, "w", encoding="utf-8") as out:
             for rl in test:
                 for j, v in enumerate(ranker.evalList(rl)):
-                    out.write("%s\t%d\t%s\n" % (rl.getID(), j, repr(float(v))))
+                    out.write("%s\t%d\t%s\n" % (rl.getID(), j, java_double_str(float(v))))
 
     def rank(self, modelFile, testFile, indriFile):        # :1168-1194: qid Q0 docno rank score indri
         ranker = self.rFact.loadRankerFromFile(modelFile)
@@ -122,7 +123,7 @@ class Evaluator:
                 sc = ranker.evalList(rl)
                 for i, j in enumerate(stable_desc_order(sc)):
                     docno = rl.get(int(j)).getDescription().replace("#", "").strip()
-                    out.write("%s Q0 %s %d %s indri\n" % (rl.getID(), docno, i + 1, repr(java_round(float(sc[int(j)]), 5))))
+                    out.write("%s Q0 %s %d %s indri\n" % (rl.getID(), docno, i + 1, java_double_str(java_round(float(sc[int(j)]), 5))))
 
     def test(self, modelFile, testFile):                   # evaluate a saved model
         ranker = self.rFact.loadRankerFromFile(modelFile)
@@ -158,7 +159,7 @@ def main(argv=None):
         elif a == "-ranker": rankerType = int(nxt())
         elif a == "-feature": featureDescriptionFile = nxt()
         elif a == "-metric2t": trainMetric = nxt()          # also captures -metric2T, exactly like the reference (:237-240)
-        elif a == "-gmax": nxt()
+        elif a == "-gmax": ERRScorer.MAX = math.pow(2.0, float(nxt()))      # eval/Evaluator.java:241-242
         elif a == "-validate": validationFile = nxt()
         elif a == "-test": testFile = nxt()
         elif a == "-save": modelFile = nxt()

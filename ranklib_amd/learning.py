@@ -24,7 +24,7 @@ import numpy as np
 
 from . import _native as N
 from ._native import RankLibError
-from .metric import TRAINABLE
+from .metric import TRAINABLE, ERRScorer
 
 logger = logging.getLogger("ranklib_amd")
 
@@ -292,6 +292,7 @@ class LambdaMART(Ranker):
         self.impacts = np.zeros(len(self.features))
         X, lab, qoff, qkey = flatten(self.samples, self.features)
         nk = int(qkey.max()) + 1 if len(qkey) else 0
+        N.set_err_max(ERRScorer.MAX)              # the reference's static ERRScorer.MAX (-gmax) reaches the kernels through the library's static
         t = N.Trainer(n_trees=cls.nTrees, n_leaves=cls.nTreeLeaves, learning_rate=cls.learningRate, n_threshold=cls.nThreshold,
                       min_leaf_support=cls.minLeafSupport, early_stop_rounds=cls.nRoundToStopEarly, metric_k=self.scorer.getK(),
                       device=cls.device, metric=metric, ranker=self._RANKER,
@@ -319,9 +320,9 @@ class LambdaMART(Ranker):
         for m in range(cls.nTrees):
             self.printLog([7], [str(m + 1)])
             _, tm, vm, stop = t.boost_round(want_tree=False)
-            self.printLog([9], [repr(java_round(float(tm), 4))])
+            self.printLog([9], [java_double_str(java_round(float(tm), 4))])
             if vm is not None:
-                self.printLog([9], [repr(java_round(float(vm), 4))])
+                self.printLog([9], [java_double_str(java_round(float(vm), 4))])
             self.flushLog()
             if stop:
                 break
@@ -399,6 +400,24 @@ class MART(LambdaMART):
 
     def name(self):                   # :41-44
         return "MART"
+
+
+def java_double_str(v):
+    """Double.toString of a Java double (score files, indri files, the per-round log table): shortest digits that round-trip (JDK >= 19),
+    decimal notation for 1e-3 <= |v| < 1e7, computerised scientific notation ("1.0E-5") otherwise; repr() switches at 1e-4 / 1e16."""
+    d = float(v)
+    if d != d:
+        return "NaN"
+    if d in (float("inf"), float("-inf")):
+        return "Infinity" if d > 0 else "-Infinity"
+    if d == 0:
+        return "-0.0" if math.copysign(1.0, d) < 0 else "0.0"
+    a = abs(d)
+    if 1e-3 <= a < 1e7:
+        r = np.format_float_positional(np.float64(d), unique=True, trim="0")
+        return r if "." in r else r + ".0"
+    m, e = np.format_float_scientific(np.float64(d), unique=True, trim="0").split("e")
+    return (m if "." in m else m + ".0") + "E" + str(int(e))
 
 
 def java_float_str(v):
@@ -503,7 +522,7 @@ class RFRanker(Ranker):
             r.init()
             r.learn()
             impacts = r.impacts if impacts is None else impacts + r.impacts
-            self.printLogLn([9, 9], ["b[%d]" % (i + 1), repr(java_round(r.getScoreOnTrainingData(), 4))])
+            self.printLogLn([9, 9], ["b[%d]" % (i + 1), java_double_str(java_round(r.getScoreOnTrainingData(), 4))])
             self.ensembles[i] = r.toString()
             self._models.append(r._model)
         self.scoreOnTrainingData = self.scorer.score(self.rank(self.samples))

@@ -95,6 +95,7 @@ def lib():
         L.ro_query_score.restype = C.c_double
         L.ro_query_score.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         L.ro_eval_flat_model.argtypes = [C.c_int32, C.c_int32] + [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
+        L.ro_set_err_max.argtypes = [C.c_double]
         L.ro_float_chain.restype = C.c_float
         L.ro_float_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         _lib = L
@@ -292,6 +293,10 @@ def feature_order(node_hash, n_features, rate):
     out = np.zeros(n_features, np.int32)
     n = lib().ro_feature_order(node_hash, n_features, rate, out.ctypes.data)
     return out[:n]
+
+
+def set_err_max(m):
+    lib().ro_set_err_max(float(m))
 
 
 def float_chain(x, idx=None):

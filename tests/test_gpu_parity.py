@@ -625,3 +625,26 @@ def test_chunked_row_upload_equals_one_shot():
         N.check(lib.rl_init(d.h))                      # rows missing
     with pytest.raises(N.RankLibError):
         N.check(lib.rl_set_rows(d.h, 0, 10, 5, Xc.ctypes.data))      # not consecutive
+
+
+def test_err_with_another_gmax_matches_the_oracle():
+    """-gmax 3: ERRScorer.MAX = 8 (eval/Evaluator.java:241-242) changes R, the lambdas and the per-round ERR"""
+    X, lab, qoff = make(3000, 8, "mslr", 31)
+    lab = np.minimum(lab, 3).astype(np.float32)
+    try:
+        O.set_err_max(8.0); N.set_err_max(8.0)
+        o = O.Oracle(X, lab, qoff, n_trees=3, n_leaves=8, metric="ERR", k=10)
+        g = N.Trainer(n_trees=3, n_leaves=8, metric="ERR", metric_k=10)
+        g.set_train(X, lab, qoff)
+        o.init(); g.init()
+        for r in range(3):
+            to, tmo, _, _ = o.round()
+            tg, tmg, _, _ = g.boost_round()
+            assert np.array_equal(g.array("LAMBDA").view(np.int64), o.lambdas().view(np.int64)), r
+            assert_same_tree(to, tg, X, "round %d" % r)
+            assert tmo == tmg
+    finally:
+        O.set_err_max(16.0); N.set_err_max(16.0)
+    o2 = O.Oracle(X, lab, qoff, n_trees=1, n_leaves=8, metric="ERR", k=10)
+    o2.init(); o2.round()
+    assert not np.array_equal(o2.lambdas(), o.lambdas())          # MAX = 16 gives other lambdas

@@ -343,3 +343,11 @@ def test_native_letor_reader_equals_the_python_reader(tmp_path):
     r1 = features.FeatureManager.readInput(str(f2), True)
     _same_lists(r0, r1)
     assert [r.getID() for r in r1] == ["b"]
+
+
+def test_java_double_str_follows_double_toString():
+    """Double.toString: decimal for 1e-3 <= |v| < 1e7, d.dE-n otherwise (score / indri files, the log table)"""
+    from ranklib_amd.learning import java_double_str as j
+    assert [j(v) for v in (5e-4, 1e-5, 0.001, 0.4000000059604645, 12345678.0, 9999999.0, 1e7, 123.0, -0.0, 0.0, 1.5e-10, 3.0e22, -2.5e-7)] == \
+        ["5.0E-4", "1.0E-5", "0.001", "0.4000000059604645", "1.2345678E7", "9999999.0", "1.0E7", "123.0", "-0.0", "0.0", "1.5E-10", "3.0E22", "-2.5E-7"]
+    assert j(float("nan")) == "NaN" and j(float("inf")) == "Infinity" and j(float("-inf")) == "-Infinity"

@@ -114,3 +114,29 @@ def test_training_rounds_identical(ranker, metric, k, seed):
         compare_round(o, r)
     so, _ = o.finish()
     assert so == r.finish()
+
+
+def test_err_max_static_changes_err_like_gmax():
+    """-gmax g sets ERRScorer.MAX = 2^g (eval/Evaluator.java:241-242): R = (2^label - 1) / MAX in score and swapChange"""
+    import numpy as np
+    import oracle_ffi as O
+    from ranklib_amd import metric as M
+    from ranklib_amd.learning import DataPoint, RankList
+    lab = np.array([3, 0, 1, 2, 0], np.float32)
+    sc = np.array([0.3, 0.9, 0.1, 0.5, 0.2])
+    try:
+        base = O.query_score("ERR", sc, lab, 10)
+        O.set_err_max(8.0)
+        M.ERRScorer.MAX = 8.0
+        got = O.query_score("ERR", sc, lab, 10)
+        assert got != base
+        order = np.argsort(-sc, kind="stable")
+        rl = RankList([DataPoint("%d qid:1 1:0" % int(lab[i])) for i in order])
+        assert got == M.ERRScorer(10).scoreOne(rl)
+        l8, w8 = O.query_lambdas_metric("ERR", sc, lab, 10)
+        O.set_err_max(16.0)
+        l16, w16 = O.query_lambdas_metric("ERR", sc, lab, 10)
+        assert not np.array_equal(l8, l16)
+    finally:
+        O.set_err_max(16.0)
+        M.ERRScorer.MAX = 16.0
