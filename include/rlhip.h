@@ -252,6 +252,8 @@ enum {
     RL_ARR_GROW_DOCS = 18,      /* int64[4] cumulative documents: accumulated into child histograms (the smaller child of every prepared
                                    node), partitioned, left children of committed splits (= what the Java accumulates: the rho of
                                    SURVEY.md 8d times N), committed split nodes (nu times N) */
+    RL_ARR_SPARSE_INFO = 19,    /* int64[4]: 16-feature groups whose root histogram comes from sparse-column entry lists (rl_csc.inc), entries,
+                                   groups read as dense rows, live columns in the sparse groups */
     RL_ARR_PHASE_CLOCKS = 16    /* int64[64][16] device wall-clock stamps (10 ns) inside the last 64 growth steps; all zero unless the
                                    library was built with -DRL_PHASE_CLOCKS (tools/phase_clocks.py) */
 };

@@ -38,7 +38,7 @@ class RlTree(C.Structure):
 RL_FLAG_FAST_LEAF, RL_FLAG_TIMING, RL_FLAG_SERIAL_CHAIN, RL_FLAG_TIMING_NODES, RL_FLAG_JAVA_ORDER = 1, 2, 4, 8, 16
 ARR = dict(LAMBDA=1, WEIGHT=2, SCORE=3, VALID_SCORE=4, NBINS=5, THRESHOLDS=6, BINS=7, ROOT_COUNT=8, ROOT_SUM=9,
            QUANT=10, ROOT_SUM_FIXED=11, NDCG_PER_QUERY=12, CHAIN_STATS=13, CHAIN_MISS=14, GROW_STATS=15, PHASE_CLOCKS=16,
-           ROOT_SUM_JAVA=17, GROW_DOCS=18)
+           ROOT_SUM_JAVA=17, GROW_DOCS=18, SPARSE_INFO=19)
 KERNEL = dict(HIST_ROOT=0, HIST_NODE=1, LAMBDA=2)
 
 # every symbol include/rlhip.h declares (tests/test_abi.py checks the .so exports all of them)
@@ -229,7 +229,7 @@ class Trainer:
         self.p.metric, self.p.ranker = RL_METRIC[metric.upper()], RL_RANKER[ranker.upper()]
         self.h = C.c_void_p()
         check(L.rl_create(C.byref(self.p), C.byref(self.h)))
-        self.cap = max(3, 2 * n_leaves - 1)          # the root always splits once (RegressionTree.java:62-67)
+        self.cap = max(3, 2 * n_leaves - 1)          # the root always splits once (RegressionTree.java:62-67); -leaf -1: set_train sizes it
         self.N = self.F = self.Q = 0
         self.Nv = 0
         self.has_valid = False
@@ -250,6 +250,8 @@ class Trainer:
         fid = None if feature_ids is None else np.ascontiguousarray(feature_ids, dtype=np.int32)
         self.N, self.F = X.shape
         self.Q = len(qoff) - 1
+        if self.p.n_leaves == -1:
+            self.cap = max(3, 2 * max(1, self.N // max(1, self.p.min_leaf_support)) - 1)
         check(lib().rl_set_train(self.h, None if chunk_rows else X.ctypes.data, self.N, self.F, labels.ctypes.data, qoff.ctypes.data, self.Q,
                                  None if fid is None else fid.ctypes.data, None if qk is None else qk.ctypes.data))
         if chunk_rows:
@@ -379,7 +381,7 @@ class Trainer:
             "THRESHOLDS": ((self.F, TS), np.float32), "BINS": ((self.F, self.N), np.uint16),
             "ROOT_COUNT": ((self.F, TS), np.int32), "ROOT_SUM": ((self.F, TS), np.float64), "ROOT_SUM_JAVA": ((self.F, TS), np.float64),
             "QUANT": ((self.N,), np.int64), "ROOT_SUM_FIXED": ((self.F, TS, 2), np.int64),
-            "NDCG_PER_QUERY": ((self.Q,), np.float64), "CHAIN_STATS": ((6,), np.int32), "GROW_STATS": ((4,), np.int32), "GROW_DOCS": ((4,), np.int64), "PHASE_CLOCKS": ((64, 16), np.int64), "CHAIN_MISS": ((2, 2 * self.p.n_leaves), np.int32),
+            "NDCG_PER_QUERY": ((self.Q,), np.float64), "CHAIN_STATS": ((6,), np.int32), "GROW_STATS": ((4,), np.int32), "GROW_DOCS": ((4,), np.int64), "SPARSE_INFO": ((4,), np.int64), "PHASE_CLOCKS": ((64, 16), np.int64), "CHAIN_MISS": ((2, 2 * max(self.p.n_leaves, 1)), np.int32),
         }
         shape, dt = shapes[name]
         out = np.zeros(shape, dt)

@@ -151,6 +151,12 @@ struct Ctx {
     // host-visible (pinned, fine-grained) growth progress: tree_seq << 32 | select_step calls in the tree << 1 | done.
     // A HINT only: the host uses it to stop enqueuing growth steps of a finished tree (extra steps are no-ops).
     unsigned long long *progress;
+    // sparse-column path of the root pass (rl_csc.inc, BASELINE.json configs[3])
+    int32_t sp_on, sp_ngroups;
+    const uint8_t *sp_grp;          // [numFG] 1 = the group's root histogram comes from its entry lists: k_hist<true> skips it
+    const int32_t *sp_glist;        // [sp_ngroups] the sparse groups
+    const uint32_t *sp_ent;         // packed entries (document-in-chunk << 16 | column-in-group << 12 | bin), ordered by (chunk, sparse group, document)
+    const int32_t *sp_off;          // [root chunks * sp_ngroups + 1] first entry of (chunk, sparse group)
     // RL_FLAG_JAVA_ORDER (rl_java_order.inc): the f64 histogram RankLib itself would hold -- per-(feature, bin) sums accumulated
     // sequentially in ascending document order, sequential prefix, right = parent - left -- decides the splits
     int32_t java;

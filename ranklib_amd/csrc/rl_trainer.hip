@@ -20,6 +20,7 @@
 #include "rl_chain.inc"
 #include "rl_kernels_round.inc"
 #include "rl_java_order.inc"
+#include "rl_csc.inc"
 #include "rl_membench.inc"
 #include "rl_dist.inc"
 #include "rl_model.h"
@@ -57,6 +58,7 @@ struct DataSet {
     double *d_ss = nullptr; float *d_sl = nullptr; int32_t *d_srel = nullptr, *d_sidx = nullptr, *d_docq = nullptr;   // ranked order (training set only)
     int32_t *d_aux_i = nullptr; double *d_aux_a = nullptr, *d_aux_b = nullptr;   // swapChange tables of MAP / ERR in ranked order
     int32_t *d_qsmall = nullptr, *d_qbig = nullptr, *d_qtiny = nullptr; int32_t n_small = 0, n_big = 0, n_tiny = 0; bool all_small = false;
+    int32_t *d_qhuge = nullptr, *d_relscratch = nullptr; int32_t n_huge = 0;      // lists beyond kLambdaBlockCap documents (k_rank_huge)
     // queries by length class for the fused lambda kernel: <= 64, <= 128, <= 192 documents, longer (tiled by 256); a block is as
     // wide as its class, so short lists do not leave most of a block idle
     int32_t *d_qcls[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; int32_t n_qcls[5] = {0, 0, 0, 0, 0};     // [4]: <= 16 documents (k_lambda_tiny)
@@ -82,6 +84,8 @@ struct rl_trainer {
     DevPool pool;
     Ctx ctx;
     EnsTree ens;
+    int32_t L_eff = 0;          // leaf budget in force: n_leaves, or floor(N / min_leaf_support) for -leaf -1
+    int64_t sp_entries = 0; int32_t sp_cols = 0;      // sparse-column path of the root pass (rl_csc.inc)
     double err_max = 16.0;      // ERRScorer.MAX when the trainer was created (rl_set_err_max)
     int32_t round = 0;          // rounds enqueued so far
     // growth progress reported by the device (Ctx::progress): the host keeps at most `step_ahead` growth steps in flight and
@@ -157,8 +161,6 @@ static int load_dataset(rl_trainer *t, DataSet &d, const float *X, int64_t n, co
     if (qkey) d.qkey.assign(qkey, qkey + Q); else d.qkey.clear();
     d.maxq = 0;
     for (int32_t q = 0; q < Q; q++) d.maxq = std::max(d.maxq, qoff[q + 1] - qoff[q]);
-    if (d.maxq > kLambdaBlockCap)
-        return fail(RL_ERR_UNSUPPORTED, "a ranked list with more than " + std::to_string(kLambdaBlockCap) + " documents");
     RL_HIP(t->pool.alloc(&d.d_X, (size_t)n * t->F));
     if (X) { RL_HIP(hipMemcpy(d.d_X, X, (size_t)n * t->F * sizeof(float), hipMemcpyHostToDevice)); d.rows_next = -1; }
     else d.rows_next = 0;
@@ -180,10 +182,16 @@ static int upload_query_side(rl_trainer *t, DataSet &d, const std::vector<double
     RL_HIP(t->pool.alloc(&d.d_ndcg, (size_t)d.Q));
     size_t tiny_min = 4096;           // lists of <= 16 documents get kernels of their own when there are enough of them
     if (const char *e = getenv("RLHIP_TINY_MIN")) tiny_min = (size_t)std::max(0, atoi(e));      // tests / tuning
-    std::vector<int32_t> small, big, tiny;
+    std::vector<int32_t> small, big, tiny, huge;
     for (int32_t q = 0; q < d.Q; q++) {
         const int n = d.qoff[q + 1] - d.qoff[q];
-        (n <= kRankTinyDocs ? tiny : n <= kLambdaWaveCap ? small : big).push_back(q);
+        (n <= kRankTinyDocs ? tiny : n <= kLambdaWaveCap ? small : n <= kLambdaBlockCap ? big : huge).push_back(q);
+    }
+    d.n_huge = (int32_t)huge.size();
+    if (!huge.empty()) {
+        RL_HIP(t->pool.alloc(&d.d_qhuge, huge.size()));
+        RL_HIP(hipMemcpy(d.d_qhuge, huge.data(), huge.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        RL_HIP(t->pool.alloc(&d.d_relscratch, (size_t)d.N));
     }
     if (tiny.size() < tiny_min) { small.insert(small.end(), tiny.begin(), tiny.end()); tiny.clear(); }
     d.n_tiny = (int32_t)tiny.size();
@@ -371,6 +379,8 @@ static int launch_rank(rl_trainer *t, DataSet &d, const double *scores, double *
                            d.all_small ? (const int *)nullptr : d.d_qsmall, d.n_small);
     if (d.n_big > 0)
         hipLaunchKernelGGL(k_rank_block, dim3(d.n_big), dim3(kRankBlockThreads), kLambdaBlockCap * 12, t->stream, a, d.d_qbig, d.n_big);
+    if (d.n_huge > 0)
+        hipLaunchKernelGGL(k_rank_huge, dim3(d.n_huge), dim3(kRankBlockThreads), 0, t->stream, a, (const int *)d.d_qhuge, d.n_huge, d.d_relscratch);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
@@ -453,9 +463,14 @@ static int enqueue_round(rl_trainer *t)
     const size_t red_lds = (size_t)c.TS * 20;
     const int rootCs = std::min(kChunk, std::max(kMinChunk, (((c.N + 63) / 64 + 255) & ~255)));   // == chunk_docs<true>(N)
     const int rootChunks = (c.N + rootCs - 1) / rootCs;
-    {   // K2 root histogram
-        ScopedTiming tm(t, RL_KERNEL_HIST_ROOT, (double)c.N * ((double)c.F * 2.0 + 8.0));
+    {   // K2 root histogram: dense groups from their 32-byte rows, groups of sparse columns from their entry lists (rl_csc.inc)
+        const double root_bytes = c.sp_on ? (double)c.N * ((double)(c.numFG - c.sp_ngroups) * kHistFG * 2.0 + 8.0) + (double)t->sp_entries * 4.0
+                                          : (double)c.N * ((double)c.F * 2.0 + 8.0);
+        ScopedTiming tm(t, RL_KERNEL_HIST_ROOT, root_bytes);
         launch_hist<true>(c, hist_gx, rootChunks, hist_lds, s);
+        if (c.sp_on) {
+            hipLaunchKernelGGL(k_hist_sp<kHistLdsStride>, dim3(c.sp_ngroups, rootChunks), dim3(kSpThreads), (size_t)kHistFG * kHistLdsStride * 8, s, c, rootCs);
+        }
     }
     // the last block of k_hist_finish runs the growth bookkeeping (select_step); node records live in LDS when they fit
     const int nodes_in_lds = (select_lds_bytes(c.L, c.NC, true, c.F, c.fs_size < c.F) <= 60 * 1024) ? 1 : 0;
@@ -721,8 +736,7 @@ int rl_create(const rl_params *p, rl_trainer **out)
         return fail(RL_ERR_UNSUPPORTED, "ranker must be RL_RANKER_LAMBDAMART (6) or RL_RANKER_MART (0)");
     if (!(p->feature_sampling_rate >= 0.0f && p->feature_sampling_rate <= 1.0f)) return fail(RL_ERR_INVALID, "feature_sampling_rate must be in [0, 1]");
     if (p->n_trees < 1) return fail(RL_ERR_INVALID, "n_trees must be >= 1");
-    if (p->n_leaves == -1) return fail(RL_ERR_UNSUPPORTED, "unlimited leaves (-leaf -1) is not built yet");
-    if (p->n_leaves < 1) return fail(RL_ERR_INVALID, "n_leaves must be >= 1");
+    if (p->n_leaves < 1 && p->n_leaves != -1) return fail(RL_ERR_INVALID, "n_leaves must be >= 1, or -1 for trees limited by min_leaf_support only");
     if (p->min_leaf_support < 1) return fail(RL_ERR_INVALID, "min_leaf_support must be >= 1");
     if (p->n_threshold != -1 && (p->n_threshold < 1 || p->n_threshold + 1 > kMaxBins))
         return fail(RL_ERR_UNSUPPORTED, "n_threshold must be -1 or in [1," + std::to_string(kMaxBins - 1) + "]");
@@ -757,6 +771,7 @@ int rl_create(const rl_params *p, rl_trainer **out)
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist_sp<kHistLdsStride>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistFG * kHistLdsStride * 8));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -852,10 +867,22 @@ int rl_init(rl_trainer *t)
     hipStream_t s = t->stream;
     const int N = (int)t->tr.N, F = t->F;
     const int Npad = (N + 127) / 128 * 128;
-    c.N = N; c.Npad = Npad; c.Q = t->tr.Q; c.F = F; c.L = t->p.n_leaves;
+    // -leaf -1 (RegressionTree.java:72 `nodes == -1`): growth ends when no leaf can be split any more.  Every leaf holds at least
+    // min_leaf_support documents, so a tree has at most floor(N / mls) leaves -- and with exactly that many none is left with 2 * mls
+    // documents: a budget of floor(N / mls) leaves never binds before the Java's own loop ends.
+    int L_eff = t->p.n_leaves;
+    if (L_eff == -1) {
+        if (t->dist) return fail(RL_ERR_UNSUPPORTED, "-leaf -1 with multi-GPU training");
+        L_eff = std::max(1, N / std::max(1, t->p.min_leaf_support));
+        const double need = (4.0 * L_eff + 2.0) * F * 264.0 * 28.0;
+        if (need > 96e9) return fail(RL_ERR_UNSUPPORTED, "-leaf -1: up to " + std::to_string(L_eff) + " leaves would need " + std::to_string((long long)(need / 1e9)) +
+                                                         " GB of node histograms; raise -mls or set -leaf");
+    }
+    t->L_eff = L_eff;
+    c.N = N; c.Npad = Npad; c.Q = t->tr.Q; c.F = F; c.L = L_eff;
     // the root is split unconditionally before the leaf budget is looked at (RegressionTree.java:62-67): even -leaf 1 gives 3 nodes
-    c.MAXN = std::max(2 * t->p.n_leaves - 1, 3);
-    c.NC = 4 * t->p.n_leaves + 2;     // node records: committed (2L-1) + prepared but never reached (see select_step)
+    c.MAXN = std::max(2 * L_eff - 1, 3);
+    c.NC = 4 * L_eff + 2;     // node records: committed (2L-1) + prepared but never reached (see select_step)
     c.mls = t->p.min_leaf_support; c.lr = t->p.learning_rate;
     c.node_div = 12; c.node_min = kMinChunk;
     c.fs_size = F; c.seed = t->p.seed;
@@ -986,6 +1013,56 @@ int rl_init(rl_trainer *t)
     RL_HIP(hipGetLastError());
     RL_HIP(hipStreamSynchronize(s));
     t->pool.release(Xt); t->pool.release(thr0); t->pool.release(fs.set);
+    {   // ---- sparse-column path of the root pass (rl_csc.inc): the groups whose live columns keep at most 1 / dens of their cells
+        // outside the mode bins get entry lists, blocked by the root pass's chunks
+        c.sp_on = 0; c.sp_ngroups = 0;
+        int dens = 3;
+        if (const char *e = getenv("RLHIP_CSC_DENS")) dens = atoi(e);               // 0 = no sparse path (tools/, tests)
+        const int rootCs = std::min(kChunk, std::max(kMinChunk, (((N + 63) / 64 + 255) & ~255)));   // == chunk_docs<true>(N)
+        const int rootChunks = (N + rootCs - 1) / rootCs;
+        if (dens > 0 && !t->dist && TS <= kHistLdsStride && c.sub == 16) {
+            std::vector<int32_t> h_cnt((size_t)F * TS), h_mode(F);
+            RL_HIP(hipMemcpy(h_cnt.data(), c.cum_cnt, h_cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            RL_HIP(hipMemcpy(h_mode.data(), d_mode, F * sizeof(int32_t), hipMemcpyDeviceToHost));
+            std::vector<int32_t> glist; std::vector<uint8_t> isg(c.numFG, 0);
+            int sp_cols = 0;
+            for (int g = 0; g < c.numFG; g++) {
+                int64_t cells = 0, live = 0;
+                for (int f = g * kHistFG; f < std::min(F, (g + 1) * kHistFG); f++) {
+                    if (h_nthr[f] <= 2) continue;                                   // dead column: its only bin is its mode bin
+                    const int m = h_mode[f];
+                    cells += (int64_t)N - ((int64_t)h_cnt[(size_t)f * TS + m] - (m > 0 ? h_cnt[(size_t)f * TS + m - 1] : 0));
+                    live++;
+                }
+                if (cells * dens <= (int64_t)N * live) { isg[g] = 1; glist.push_back(g); sp_cols += (int)live; }   // groups of dead columns too: nothing to read
+            }
+            if (!glist.empty()) {
+                const int nsg = (int)glist.size();
+                int32_t *d_glist = nullptr, *d_cnt = nullptr, *d_off = nullptr; uint8_t *d_isg = nullptr; uint32_t *d_ent = nullptr;
+                RL_HIP(t->pool.alloc(&d_glist, (size_t)nsg)); RL_HIP(t->pool.alloc(&d_cnt, (size_t)nsg * rootChunks)); RL_HIP(t->pool.alloc(&d_off, (size_t)nsg * rootChunks + 1));
+                RL_HIP(t->pool.alloc(&d_isg, (size_t)c.numFG));
+                RL_HIP(hipMemcpy(d_glist, glist.data(), nsg * sizeof(int32_t), hipMemcpyHostToDevice));
+                RL_HIP(hipMemcpy(d_isg, isg.data(), c.numFG, hipMemcpyHostToDevice));
+                hipLaunchKernelGGL(k_sp_build<false>, dim3(nsg, rootChunks), dim3(kThreads), 0, s, c, (const int32_t *)d_glist, nsg, rootCs, d_cnt, (const int32_t *)nullptr, (uint32_t *)nullptr);
+                RL_HIP(hipGetLastError());
+                RL_HIP(hipStreamSynchronize(s));
+                std::vector<int32_t> cnt((size_t)nsg * rootChunks), off((size_t)nsg * rootChunks + 1);
+                RL_HIP(hipMemcpy(cnt.data(), d_cnt, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+                int64_t E = 0;
+                for (size_t i = 0; i < cnt.size(); i++) { off[i] = (int32_t)E; E += cnt[i]; }
+                if (E < 2000000000ll) {
+                    off[cnt.size()] = (int32_t)E;
+                    RL_HIP(t->pool.alloc(&d_ent, (size_t)E));
+                    RL_HIP(hipMemcpy(d_off, off.data(), off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                    hipLaunchKernelGGL(k_sp_build<true>, dim3(nsg, rootChunks), dim3(kThreads), 0, s, c, (const int32_t *)d_glist, nsg, rootCs, (int32_t *)nullptr, (const int32_t *)d_off, d_ent);
+                    RL_HIP(hipGetLastError());
+                    RL_HIP(hipStreamSynchronize(s));
+                    c.sp_on = 1; c.sp_ngroups = nsg; c.sp_grp = d_isg; c.sp_glist = d_glist; c.sp_ent = d_ent; c.sp_off = d_off;
+                    t->sp_entries = E; t->sp_cols = sp_cols;
+                }
+            }
+        }
+    }
 
     // ---- query side: ideal DCGs with the qid-keyed cache quirk (NDCGScorer.java:114-122,134-143) --
     int maxq = std::max(t->tr.maxq, t->has_valid ? t->va.maxq : 0);
@@ -1420,6 +1497,12 @@ int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes)
     case RL_ARR_NDCG_PER_QUERY: src = c.ndcg_q; bytes = (size_t)c.Q * 8; break;
     case RL_ARR_GROW_STATS: src = c.grow_stats; bytes = 16; break;
     case RL_ARR_GROW_DOCS: src = c.grow_docs; bytes = 32; break;
+    case RL_ARR_SPARSE_INFO: {
+        const int64_t v[4] = {c.sp_on ? c.sp_ngroups : 0, t->sp_entries, c.sp_on ? c.numFG - c.sp_ngroups : c.numFG, t->sp_cols};
+        if (cap_bytes < (int64_t)sizeof(v)) return fail(RL_ERR_INVALID, "output buffer too small");
+        memcpy(out, v, sizeof(v));
+        return RL_OK;
+    }
     case RL_ARR_PHASE_CLOCKS: src = c.clk; bytes = 64 * 16 * sizeof(long long); break;
     case RL_ARR_CHAIN_STATS: {
         if (cap_bytes < 24) return fail(RL_ERR_INVALID, "output buffer too small");

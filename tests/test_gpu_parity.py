@@ -577,20 +577,59 @@ def test_bad_inputs_are_rejected_with_ranklib_style_errors():
 
 
 @pytest.mark.gpu
-def test_sparse_700_feature_shape_matches_the_oracle():
-    """Yahoo-set1 shape in small: 700 columns, 175 of them all zero (one threshold + MAX_VALUE, never
-    split on), the rest 85 % zeros; the tree learner densifies everything, so only the column count changes"""
+@pytest.mark.parametrize("mode", ["sparse", "dense"])
+def test_sparse_700_feature_shape_matches_the_oracle(mode, monkeypatch):
+    """Yahoo-set1 shape (BASELINE.json configs[3]) in small: 700 columns, 175 of them all zero (one threshold + MAX_VALUE,
+    never split on), the rest 85 % zeros.  The tree learner densifies everything (learning/SparseDataPoint.java:82-95), so only the
+    column count changes for the oracle; the GPU's root pass runs its sparse-column path (rl_csc.inc: entry lists instead of rows) or,
+    with RLHIP_CSC_DENS=0, the dense rows.  Both must give the oracle's trees / scores / metrics: the paths are bit-identical."""
+    if mode == "dense":
+        monkeypatch.setenv("RLHIP_CSC_DENS", "0")
     X, lab, qoff = make(6000, 700, "yahoo", 31)
-    o, g = pair(X, lab, qoff, n_trees=3, n_leaves=12)
+    o, g = pair(X, lab, qoff, n_trees=4, n_leaves=12)
     o.init(); g.init()
     nb = g.array("NBINS")
     assert (nb[np.abs(X).sum(0) == 0] == 2).all()
-    for r in range(3):
+    info = g.array("SPARSE_INFO")
+    if mode == "dense":
+        assert info[0] == 0 and info[1] == 0 and info[2] == 44
+    else:
+        nzv = int((X[:, nb > 2] != 0).sum())
+        assert info[0] >= 40 and info[0] + info[2] == 44 and info[3] <= int((nb > 2).sum()), info   # (nearly) every group is sparse at 15 % density
+        assert 0.5 * nzv <= info[1] <= nzv, (info, nzv)         # one entry per non-zero value of the sparse groups (the zero bin is the mode bin)
+    for r in range(4):
         to, tmo, _, _ = o.round()
         tg, tmg, _, _ = g.boost_round()
         assert_same_tree(to, tg, X, "round %d" % r)
         assert np.array_equal(g.array("SCORE").view(np.int64), o.scores().view(np.int64))
         assert np.float32(tmo).view(np.uint32) == np.float32(tmg).view(np.uint32)
+        # the root histogram: the same exact sums whichever path accumulated them
+        tot = int(g.array("QUANT").astype(object).sum())
+        fixed = g.array("ROOT_SUM_FIXED")
+        for f in np.nonzero(nb > 2)[0][:60]:
+            hi, lo = int(fixed[f, nb[f] - 1, 0]), int(fixed[f, nb[f] - 1, 1]) & 0xFFFFFFFFFFFFFFFF
+            assert hi * 2 ** 64 + lo == tot, (r, f)
+
+
+def test_mixed_sparse_and_dense_columns():
+    """a group of sparse columns (entry lists), a dense group (rows) and a mixed one (stays dense), dead columns among them"""
+    rng = np.random.default_rng(5)
+    X, lab, qoff = make(9000, 40, "mslr", 41)
+    X = X.copy()
+    for f in list(range(0, 16)) + list(range(32, 40, 2)):
+        X[rng.random(9000) < 0.9, f] = 0.0           # 90 % zeros: group 0 is sparse, group 2 half and half
+    X[:, 7] = 0.0                                    # dead columns
+    X[:, 20] = 0.0
+    o, g = pair(X, lab, qoff, n_trees=4, n_leaves=16)
+    o.init(); g.init()
+    info = g.array("SPARSE_INFO")
+    assert info[0] >= 1 and info[2] >= 1 and info[0] + info[2] == 3, info             # 40 columns = 3 groups
+    for r in range(4):
+        to, tmo, _, _ = o.round()
+        tg, tmg, _, _ = g.boost_round()
+        assert_same_tree(to, tg, X, "round %d" % r)
+        assert np.array_equal(g.array("SCORE").view(np.int64), o.scores().view(np.int64))
+        assert tmo == tmg
 
 
 @pytest.mark.gpu
@@ -648,3 +687,53 @@ def test_err_with_another_gmax_matches_the_oracle():
     o2 = O.Oracle(X, lab, qoff, n_trees=1, n_leaves=8, metric="ERR", k=10)
     o2.init(); o2.round()
     assert not np.array_equal(o2.lambdas(), o.lambdas())          # MAX = 16 gives other lambdas
+
+
+@pytest.mark.parametrize("metric,n_long", [("NDCG", 12000), ("MAP", 5600)])
+def test_ranked_lists_beyond_5000_documents(metric, n_long):
+    """RankLib puts no limit on a ranked list's length (LambdaMART.java:361-396): lists past the LDS capacity of the block-per-query
+    ranking kernel go through k_rank_huge (tiled rank by counting); the lambda kernels tile over the columns anyway."""
+    rng = np.random.default_rng(12)
+    sizes = [n_long, 40, 700, 9, 5100]
+    qoff = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    n = int(qoff[-1])
+    X = rng.random((n, 5)).astype(np.float32)
+    X[:, 0] = np.floor(X[:, 0] * 12)
+    lab = np.clip(np.floor(X[:, 0] / 3 + X[:, 1] * 2 + rng.random(n)), 0, 4).astype(np.float32)
+    k = 0 if metric == "MAP" else 10
+    o = O.Oracle(X, lab, qoff, n_trees=3, n_leaves=8, metric=metric, k=k)
+    g = N.Trainer(n_trees=3, n_leaves=8, metric=metric, metric_k=k)
+    g.set_train(X, lab, qoff)
+    o.init(); g.init()
+    for r in range(3):
+        to, tmo, _, _ = o.round()
+        tg, tmg, _, _ = g.boost_round()
+        assert np.array_equal(g.array("LAMBDA").view(np.int64), o.lambdas().view(np.int64)), r
+        assert np.array_equal(g.array("WEIGHT").view(np.int64), o.weights().view(np.int64)), r
+        assert_same_tree(to, tg, X, "round %d" % r)
+        assert np.array_equal(g.array("SCORE").view(np.int64), o.scores().view(np.int64)), r
+        assert tmo == tmg, r
+    so, _ = o.finish()
+    sg, _ = g.finish()
+    assert so == sg
+
+
+@pytest.mark.parametrize("mls,n_docs,strict", [(1, 300, True), (7, 2000, True), (40, 6000, False)])
+def test_unlimited_leaves(mls, n_docs, strict):
+    """-leaf -1 (RegressionTree.java:72 `nodes == -1`): the tree grows until no leaf can be split; only -mls bounds it.  Trees this deep
+    end in nodes of a few documents, where different partitions tie exactly all the time: those cases run under RL_FLAG_JAVA_ORDER,
+    which resolves ties as the Java does, and must give IDENTICAL trees."""
+    X, lab, qoff = make(n_docs, 6, "ns", 51)
+    o = O.Oracle(X, lab, qoff, n_trees=3, n_leaves=-1, mls=mls)
+    g = N.Trainer(n_trees=3, n_leaves=-1, min_leaf_support=mls, flags=N.RL_FLAG_JAVA_ORDER if strict else 0)
+    g.set_train(X, lab, qoff)
+    o.init(); g.init()
+    for r in range(3):
+        to, tmo, _, _ = o.round()
+        tg, tmg, _, _ = g.boost_round()
+        ties = assert_equivalent(to, tg, X, "round %d" % r)
+        assert ties == 0 or not strict
+        assert to.n_nodes > 2 * 10 - 1                       # more leaves than the default budget
+        assert np.array_equal(g.array("SCORE").view(np.int64), o.scores().view(np.int64)), r
+        assert tmo == tmg, r
+    assert "## No. of leaves = -1" in g.model_text()
