@@ -249,6 +249,7 @@ def main():
         g.sync()
     g.reset_timing()
     gd0 = g.array("GROW_DOCS").astype(np.float64)
+    ds0 = g.dist_stats().astype(np.float64)
     barrier()
     t0 = time.perf_counter()
     g.boost_rounds_async(args.steps)
@@ -265,6 +266,7 @@ def main():
     ms_lam, n_lam, _ = g.timing("LAMBDA")
     gs = g.array("GROW_STATS")
     gd = (g.array("GROW_DOCS").astype(np.float64) - gd0) / max(args.steps, 1)      # documents per round: built, partitioned, Java-left, Java-split
+    ds = (g.dist_stats().astype(np.float64) - ds0) / max(args.steps, 1)             # exchange of this rank per round: all-reduce calls / bytes, all-gather calls / bytes
 
     # ---- after the headline region: sustained rate over a long run, then a few rounds with events around every node-histogram launch
     sustained = None
@@ -374,6 +376,9 @@ def main():
             }
         out["kernel_ms_per_round"] = {"hist_root": ms_root / args.steps, "lambda": ms_lam / args.steps,
                                       "hist_nodes": node["ms_per_round"] if node else None}
+    if world > 1:
+        out["config"]["exchange_per_round_rank0"] = {"allreduce_calls": ds[0], "allreduce_bytes": ds[1], "allgather_calls": ds[2], "allgather_bytes_received": ds[3],
+                                                     "note": "payload sizes handed to RCCL by this rank (histogram limbs per growth step; lambda / weight of the leaves; per-query metric values)"}
     if sustained is not None:
         out["config"]["sustained_rounds_per_s"] = sustained
         out["config"]["sustained_over_rounds"] = args.sustain

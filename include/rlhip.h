@@ -212,9 +212,14 @@ void rl_letor_destroy(rl_letor *l);
 /* ---- multi-GPU (one process per GPU; queries sharded across ranks) ---------- */
 #define RL_UNIQUE_ID_BYTES 128
 int rl_dist_unique_id(void *id_out /* RL_UNIQUE_ID_BYTES */);       /* call on rank 0, broadcast out of band */
-/* Must be called before rl_init.  Each rank passes ITS shard of the queries to rl_set_train; the
- * per-split histograms (and the few per-round scalars) are summed across ranks with RCCL. */
+/* Must be called before rl_init.  Each rank passes ITS shard of the queries to rl_set_train (and, if there is a validation set, its
+ * shard of the validation queries to rl_set_validation: every rank or none); the per-split histograms (and the few per-round scalars)
+ * are summed across ranks with RCCL, per-query metric values are gathered in rank order. */
 int rl_dist_init(rl_trainer *t, const void *id, int32_t rank, int32_t n_ranks);
+
+/* Exchange volume of this rank since rl_dist_init: out[0..3] = all-reduce calls, all-reduce payload bytes, all-gather calls, all-gather
+ * bytes received (zeros for an unsharded trainer).  bench.py prints the per-round figures for N > 1. */
+int rl_dist_stats(const rl_trainer *t, int64_t *out);
 
 /* The same sharded training over a caller-supplied transport instead of RCCL (gloo, MPI, shared memory ...):
  * the library stages each exchange through host memory and calls back.  Slower (a host synchronisation per

@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "rl_set_train", "rl_set_validation", "rl_set_rows", "rl_init", "rl_boost_round", "rl_boost_rounds_async", "rl_sync",
     "rl_finish", "rl_num_trees", "rl_get_tree", "rl_get_round_metrics", "rl_best_validation", "rl_predict",
     "rl_model_to_text", "rl_model_from_text", "rl_model_destroy", "rl_model_num_trees", "rl_model_features",
-    "rl_model_predict", "rl_model_predict_device", "rl_dist_unique_id", "rl_dist_init", "rl_dist_init_callback", "rl_bin_stride", "rl_quant_exponent", "rl_get_array", "rl_debug_exp", "rl_debug_float_chain",
+    "rl_model_predict", "rl_model_predict_device", "rl_dist_unique_id", "rl_dist_init", "rl_dist_init_callback", "rl_dist_stats", "rl_bin_stride", "rl_quant_exponent", "rl_get_array", "rl_debug_exp", "rl_debug_float_chain",
     "rl_letor_parse", "rl_letor_info", "rl_letor_arrays", "rl_letor_rows", "rl_letor_destroy",
     "rl_get_timing", "rl_reset_timing", "rl_set_timing_flags", "rl_debug_membench", "rl_set_err_max",
 ]
@@ -100,6 +100,7 @@ def lib():
     L.rl_model_predict_device.argtypes = [vp, vp, i64, i32, vp, vp]
     L.rl_dist_unique_id.argtypes = [vp]
     L.rl_dist_init.argtypes = [vp, vp, i32, i32]
+    L.rl_dist_stats.argtypes = [vp, vp]
     L.rl_dist_init_callback.argtypes = [vp, i32, i32, HOST_ALLREDUCE, HOST_ALLGATHER, vp]
     L.rl_bin_stride.argtypes = [vp, C.POINTER(i32)]
     L.rl_quant_exponent.argtypes = [vp, C.POINTER(i32)]
@@ -280,6 +281,12 @@ class Trainer:
     def dist_init(self, uid, rank, n_ranks):
         """RCCL transport; every rank passes ITS shard of the queries to set_train (before init)"""
         check(lib().rl_dist_init(self.h, uid, rank, n_ranks))
+
+    def dist_stats(self):
+        """[all-reduce calls, all-reduce bytes, all-gather calls, all-gather bytes received] of this rank so far"""
+        out = np.zeros(4, np.int64)
+        check(lib().rl_dist_stats(self.h, out.ctypes.data))
+        return out
 
     def dist_init_callback(self, rank, n_ranks, allreduce, allgather):
         """host transport: allreduce(np_array, op) reduces in place, allgather(np_uint8_in) -> np_uint8 [n_ranks*len]"""

@@ -117,6 +117,9 @@ struct rl_trainer {
     ChainBufs gchain;                          // float chains over the all-gathered leaf values
     double *d_gx = nullptr; int32_t *d_gls = nullptr; int32_t lsstride = 0; float *d_gres = nullptr;
     double *d_qsend = nullptr, *d_qgath = nullptr, *d_qcat = nullptr; int32_t *d_allQ = nullptr;
+    // the same for the validation set (sharded by query like the training set)
+    int32_t vQglobal = 0, vQmax = 0; double *d_vqsend = nullptr, *d_vqgath = nullptr, *d_vqcat = nullptr; int32_t *d_vallQ = nullptr;
+    double dist_timeout_s = 300.0;             // a rank that waits this long for its own device to report a growth step gives up (RLHIP_DIST_TIMEOUT_S)
 };
 
 namespace rl {
@@ -400,14 +403,16 @@ static void launch_hist(const Ctx &c, int gx, int gy, size_t lds, hipStream_t s)
 }
 
 // multi-GPU: per-query values of all ranks in global query order (ranks hold ascending contiguous query ranges)
-static int gather_queries(rl_trainer *t, const double *local, const double **out)
+static int gather_queries(rl_trainer *t, const double *local, const double **out, bool valid = false)
 {
     hipStream_t s = t->stream;
-    hipLaunchKernelGGL(k_copy_f64, dim3(std::max(1, std::min(1024, (t->tr.Q + kThreads - 1) / kThreads))), dim3(kThreads), 0, s, local, t->d_qsend, t->tr.Q);
-    int rc = t->dist->allgather(t->d_qsend, t->d_qgath, (size_t)t->Qmax * sizeof(double), s);
+    const int Q = valid ? t->va.Q : t->tr.Q, Qmax = valid ? t->vQmax : t->Qmax;
+    double *snd = valid ? t->d_vqsend : t->d_qsend, *gat = valid ? t->d_vqgath : t->d_qgath, *cat = valid ? t->d_vqcat : t->d_qcat;
+    hipLaunchKernelGGL(k_copy_f64, dim3(std::max(1, std::min(1024, (Q + kThreads - 1) / kThreads))), dim3(kThreads), 0, s, local, snd, Q);
+    int rc = t->dist->allgather(snd, gat, (size_t)Qmax * sizeof(double), s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_concat_ranks, dim3(64), dim3(kThreads), 0, s, (const double *)t->d_qgath, (const int32_t *)t->d_allQ, t->n_ranks, t->Qmax, t->d_qcat);
-    *out = t->d_qcat;
+    hipLaunchKernelGGL(k_concat_ranks, dim3(64), dim3(kThreads), 0, s, (const double *)gat, (const int32_t *)(valid ? t->d_vallQ : t->d_allQ), t->n_ranks, Qmax, cat);
+    *out = cat;
     return RL_OK;
 }
 
@@ -506,11 +511,17 @@ static int enqueue_round(rl_trainer *t)
                 // <= it - step_ahead.  The word keeps (step at which `done` was set, done) once the tree is finished, so a rank
                 // that looks early and one that looks late take the same decision at the same `it`.
                 unsigned spins = 0;
+                const auto t0w = std::chrono::steady_clock::now();
                 while (w < want && !finished(w)) {
                     w = __atomic_load_n(t->h_progress, __ATOMIC_ACQUIRE);
                     if ((++spins & 0xfffff) == 0) {
                         const hipError_t q = hipStreamQuery(s);
                         if (q != hipSuccess && q != hipErrorNotReady) return fail(RL_ERR_HIP, std::string("device error while growing a tree: ") + hipGetErrorString(q));
+                        // the wait ends when THIS rank's device finishes a growth step, which needs every other rank's share of the step's
+                        // collective: a rank that died or fell behind for good must surface as an error here, not as a hang
+                        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0w).count() > t->dist_timeout_s)
+                            return fail(RL_ERR_COMM, "timed out after " + std::to_string((int)t->dist_timeout_s) + " s waiting for growth step " + std::to_string(it - t->step_ahead) +
+                                                     " of tree " + std::to_string(t->tree_seq) + " (a rank of the job is missing from a collective?)");
                     }
                 }
                 const int step_w = (int)((unsigned)(w & 0xffffffffull) >> 1);
@@ -609,7 +620,12 @@ static int enqueue_round(rl_trainer *t)
                            t->ens, c.MAXN, m, (const float *)t->va.d_X, (int)t->va.N, c.F, c.lr, t->va.d_scores);
         rc = launch_rank(t, t->va, t->va.d_scores, t->va.d_ndcg, false);
         if (rc != RL_OK) return rc;
-        enqueue_metric_mean(t, t->va.d_ndcg, t->va.Q, c.round_metric + 2 * (size_t)m + 1);
+        if (t->dist) {      // every rank holds a shard of the validation lists: the float mean runs over all of them in list order
+            const double *gq = nullptr;
+            rc = gather_queries(t, t->va.d_ndcg, &gq, true);
+            if (rc != RL_OK) return rc;
+            enqueue_metric_mean(t, gq, t->vQglobal, c.round_metric + 2 * (size_t)m + 1);
+        } else enqueue_metric_mean(t, t->va.d_ndcg, t->va.Q, c.round_metric + 2 * (size_t)m + 1);
     }
     RL_HIP(hipGetLastError());
     t->round = m + 1;
@@ -1114,6 +1130,7 @@ int rl_init(rl_trainer *t)
     RL_HIP(hipMemset(c.st, 0, sizeof(TreeState)));
     t->tree_seq = 0;
     if (const char *e = getenv("RLHIP_STEP_AHEAD")) t->step_ahead = std::max(0, atoi(e));     // tuning knob
+    if (const char *e = getenv("RLHIP_DIST_TIMEOUT_S")) t->dist_timeout_s = std::max(1.0, atof(e));
     // the progress word is an optimisation: without host-visible coherent memory the host simply enqueues every step
     c.progress = nullptr;
     if (!t->h_progress && hipHostMalloc((void **)&t->h_progress, sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
@@ -1171,27 +1188,34 @@ int rl_init(rl_trainer *t)
         int64_t Nmax = N;
         t->Qglobal = t->tr.Q; t->Qmax = t->tr.Q; t->Nglobal = N; c.Nglobal = N;
         if (t->dist) {      // sizes of every rank
-            if (t->has_valid) return fail(RL_ERR_UNSUPPORTED, "validation data with multi-GPU training is not built yet");
+            // every rank either has a validation shard or none has (checked below through the gathered sizes)
             int32_t *d_sz = nullptr, *d_all = nullptr;
-            RL_HIP(t->pool.alloc(&d_sz, (size_t)2)); RL_HIP(t->pool.alloc(&d_all, (size_t)2 * t->n_ranks));
-            const int32_t mine[2] = {N, t->tr.Q};
+            RL_HIP(t->pool.alloc(&d_sz, (size_t)4)); RL_HIP(t->pool.alloc(&d_all, (size_t)4 * t->n_ranks));
+            const int32_t mine[4] = {N, t->tr.Q, t->has_valid ? t->va.Q : 0, t->has_valid ? 1 : 0};
             RL_HIP(hipMemcpy(d_sz, mine, sizeof(mine), hipMemcpyHostToDevice));
             int rcd = t->dist->allgather(d_sz, d_all, sizeof(mine), s); if (rcd) return rcd;
-            std::vector<int32_t> all((size_t)2 * t->n_ranks);
+            std::vector<int32_t> all((size_t)4 * t->n_ranks), all_vQ;
             RL_HIP(hipStreamSynchronize(s));
             RL_HIP(hipMemcpy(all.data(), d_all, all.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-            t->all_N.clear(); t->all_Q.clear(); t->Nglobal = 0; t->Qglobal = 0; t->Qmax = 0;
+            t->all_N.clear(); t->all_Q.clear(); t->Nglobal = 0; t->Qglobal = 0; t->Qmax = 0; t->vQglobal = 0; t->vQmax = 0;
             for (int r = 0; r < t->n_ranks; r++) {
-                t->all_N.push_back(all[2 * r]); t->all_Q.push_back(all[2 * r + 1]);
-                t->Nglobal += all[2 * r]; t->Qglobal += all[2 * r + 1];
-                Nmax = std::max<int64_t>(Nmax, all[2 * r]); t->Qmax = std::max(t->Qmax, all[2 * r + 1]);
+                t->all_N.push_back(all[4 * r]); t->all_Q.push_back(all[4 * r + 1]); all_vQ.push_back(all[4 * r + 2]);
+                t->Nglobal += all[4 * r]; t->Qglobal += all[4 * r + 1]; t->vQglobal += all[4 * r + 2];
+                Nmax = std::max<int64_t>(Nmax, all[4 * r]); t->Qmax = std::max(t->Qmax, all[4 * r + 1]); t->vQmax = std::max(t->vQmax, all[4 * r + 2]);
+                if ((all[4 * r + 3] != 0) != t->has_valid) return fail(RL_ERR_INVALID, "multi-GPU training: either every rank sets a validation shard or none does");
+            }
+            if (t->has_valid) {
+                RL_HIP(t->pool.alloc(&t->d_vqsend, (size_t)t->vQmax)); RL_HIP(t->pool.alloc(&t->d_vqgath, (size_t)t->n_ranks * t->vQmax));
+                RL_HIP(t->pool.alloc(&t->d_vqcat, (size_t)t->vQglobal)); RL_HIP(t->pool.alloc(&t->d_vallQ, (size_t)t->n_ranks));
+                RL_HIP(hipMemcpy(t->d_vallQ, all_vQ.data(), t->n_ranks * sizeof(int32_t), hipMemcpyHostToDevice));
+                RL_HIP(hipMemset(t->d_vqsend, 0, (size_t)t->vQmax * sizeof(double)));
             }
             if (t->Nglobal >= (int64_t)2147483647 - 4096) return fail(RL_ERR_UNSUPPORTED, "more than 2^31 documents in total");
             c.Nglobal = (int32_t)t->Nglobal;
         }
         int rc = alloc_chain(t, t->leaf_chain, c.MAXN + 1, 2, Nmax, true);
         if (rc) return rc;
-        rc = alloc_chain(t, t->metric_chain, 1, 1, std::max(t->Qglobal, t->has_valid ? t->va.Q : 0));
+        rc = alloc_chain(t, t->metric_chain, 1, 1, std::max(t->Qglobal, t->has_valid ? std::max(t->va.Q, t->vQglobal) : 0));
         if (rc) return rc;
         RL_HIP(t->pool.alloc(&t->d_seg_buf, (size_t)c.MAXN + 2));
         if (t->dist) {
@@ -1289,9 +1313,10 @@ static int final_score(rl_trainer *t, DataSet &d, double *out)
     if (rc) return rc;
     if (t->dist) {
         const double *gq = nullptr;
-        rc = gather_queries(t, d.d_ndcg, &gq);
+        const bool valid = (&d == &t->va);
+        rc = gather_queries(t, d.d_ndcg, &gq, valid);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_double_mean, dim3(1), dim3(64), 0, s, gq, t->Qglobal, t->d_mean);
+        hipLaunchKernelGGL(k_double_mean, dim3(1), dim3(64), 0, s, gq, valid ? t->vQglobal : t->Qglobal, t->d_mean);
     } else hipLaunchKernelGGL(k_double_mean, dim3(1), dim3(64), 0, s, (const double *)d.d_ndcg, d.Q, t->d_mean);
     RL_HIP(hipGetLastError());
     RL_HIP(hipStreamSynchronize(s));
@@ -1438,6 +1463,15 @@ int rl_dist_init(rl_trainer *t, const void *id, int32_t rank, int32_t n_ranks)
     b->rank = rank; b->n = n_ranks;
     t->rank = rank; t->n_ranks = n_ranks;
     t->dist = std::move(b);
+    return RL_OK;
+}
+
+int rl_dist_stats(const rl_trainer *t, int64_t *out)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    if (!out) return fail(RL_ERR_INVALID, "null argument");
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (t->dist) { out[0] = t->dist->n_allreduce; out[1] = t->dist->b_allreduce; out[2] = t->dist->n_allgather; out[3] = t->dist->b_allgather; }
     return RL_OK;
 }
 

@@ -19,26 +19,49 @@ def main():
 
     out_path, n_docs, n_feat, kind, seed, leaves, rounds = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
     ranker, metric, k = (sys.argv[8], sys.argv[9], int(sys.argv[10])) if len(sys.argv) > 10 else ("LAMBDAMART", "NDCG", 10)
+    opts = sys.argv[11].split(",") if len(sys.argv) > 11 else []       # "valid": sharded validation set + early stopping; "rccl": RCCL transport
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     X, lab, qoff = synth.make_dataset(n_docs, n_feat, kind, seed_offset=seed)
     Xs, ls, qs = D.shard(X, lab, qoff, rank, world)
     tr = D.TorchHostTransport()
-    g = N.Trainer(n_trees=rounds, n_leaves=leaves, ranker=ranker, metric=metric, metric_k=k)
+    estop = 1 if "valid" in opts else 100
+    g = N.Trainer(n_trees=rounds, n_leaves=leaves, ranker=ranker, metric=metric, metric_k=k, early_stop_rounds=estop)
     g.set_train(Xs, ls, qs)
-    g.dist_init_callback(rank, world, tr.allreduce, tr.allgather)
+    if "valid" in opts:
+        Xv, lv, qv = synth.make_dataset(n_docs // 3, n_feat, kind, seed_offset=seed + 77)
+        lv = lv[::-1].copy()                  # labels unrelated to the features: the validation metric wanders and the early stop fires
+        g.set_validation(*D.shard(Xv, lv, qv, rank, world))
+    if "rccl" in opts:
+        # RCCL transport with every rank on the SAME device (the only GPU of the test box).  RCCL may refuse that ("Duplicate GPU
+        # detected"): the test then only proves that ncclCommInitRank was reached with N ranks and failed cleanly.
+        box = [g.dist_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        try:
+            g.dist_init(box[0], rank, world)
+        except N.RankLibError as ex:
+            if rank == 0:
+                np.savez(out_path, refused=str(ex))
+            dist.barrier()
+            dist.destroy_process_group()
+            return
+    else:
+        g.dist_init_callback(rank, world, tr.allreduce, tr.allgather)
     g.init()
-    trees, mets = [], []
+    trees, mets, vmets = [], [], []
     for _ in range(rounds):
-        t, tm, _, _ = g.boost_round()
-        trees.append(t.trimmed()); mets.append(float(tm))
-    final, _ = g.finish()
+        t, tm, vm, stop = g.boost_round()
+        trees.append(t.trimmed()); mets.append(float(tm)); vmets.append(float(vm) if vm is not None else 0.0)
+        if stop:
+            break
+    final, vfinal = g.finish()
     sc = g.array("SCORE")
     parts = [None] * world
     dist.all_gather_object(parts, sc)
     stats = g.array("CHAIN_STATS")
     if rank == 0:
-        np.savez(out_path, scores=np.concatenate(parts), mets=np.array(mets), final=final, stats=stats,
+        np.savez(out_path, scores=np.concatenate(parts), mets=np.array(mets), vmets=np.array(vmets), final=final, vfinal=(vfinal or 0.0), kept=g.num_trees(),
+                 dist_stats=g.dist_stats(), stats=stats,
                  **{"t%d_%s" % (i, k): v for i, t in enumerate(trees) for k, v in t.items()})
     dist.barrier()
     dist.destroy_process_group()

@@ -89,3 +89,54 @@ def test_k_shards_equal_one_shard(world, ranker, metric, k, cfg, tmp_path):
     rounds = CFG[5]
     trees = [{k: z["t%d_%s" % (i, k)] for k in ("feature", "threshold", "left", "right", "output", "deviance", "count")} for i in range(rounds)]
     same(ref, (trees, [float(v) for v in z["mets"]], z["scores"], float(z["final"])))
+
+
+def _run_workers(world, cfg, out, extra, port):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), out] + [str(v) for v in cfg] + ["LAMBDAMART", "NDCG", "10", extra]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return np.load(out, allow_pickle=True)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_validation_set_under_sharding(world, tmp_path):
+    """training AND validation lists sharded over the ranks (learning/tree/LambdaMART.java:228-250 has no such notion: one JVM): per-round
+    validation metric, early stop, rollback and the kept trees equal the one-GPU run's"""
+    cfg = (9000, 16, "ns", 9, 8, 30)
+    X, lab, qoff = synth.make_dataset(cfg[0], cfg[1], cfg[2], seed_offset=cfg[3])
+    Xv, lv, qv = synth.make_dataset(cfg[0] // 3, cfg[1], cfg[2], seed_offset=cfg[3] + 77)
+    lv = lv[::-1].copy()                      # as tests/dist_worker.py does
+    g = N.Trainer(n_trees=cfg[5], n_leaves=cfg[4], early_stop_rounds=1)
+    g.set_train(X, lab, qoff); g.set_validation(Xv, lv, qv); g.init()
+    mets, vmets = [], []
+    for _ in range(cfg[5]):
+        t, tm, vm, stop = g.boost_round()
+        mets.append(float(tm)); vmets.append(float(vm))
+        if stop:
+            break
+    final, vfinal = g.finish()
+    z = _run_workers(world, cfg, str(tmp_path / "v.npz"), "valid", 29531 + world)
+    assert [float(v) for v in z["mets"]] == mets and [float(v) for v in z["vmets"]] == vmets
+    assert float(z["final"]) == final and float(z["vfinal"]) == vfinal and int(z["kept"]) == g.num_trees()
+    assert len(mets) < cfg[5], "the early stop never fired: the case does not test the rollback"
+    st = z["dist_stats"]
+    assert st[0] > 0 and st[2] > 0
+
+
+def test_rccl_transport_with_two_ranks():
+    """ncclCommInitRank with N = 2 through the dlsym'ed entry points (128-byte ncclUniqueId by value, rl_dist.inc).  The test box has ONE
+    GPU: if RCCL accepts two ranks on it the sharded run must equal the one-GPU run; if it refuses ("Duplicate GPU"), the refusal must
+    arrive as a clean RL_ERR_COMM on every rank -- no crash, no hang -- which is all a one-GPU box can prove about the call."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        z = _run_workers(2, CFG, os.path.join(d, "r.npz"), "rccl", 29541)
+        if "refused" in z:
+            msg = str(z["refused"])
+            assert "ncclCommInitRank" in msg, msg
+            print("RCCL refused two ranks on one device:", msg)
+        else:
+            ref = single(*CFG)
+            trees = [{k: z["t%d_%s" % (i, k)] for k in ("feature", "threshold", "left", "right", "output", "deviance", "count")} for i in range(CFG[5])]
+            same(ref, (trees, [float(v) for v in z["mets"]], z["scores"], float(z["final"])))
