@@ -79,10 +79,17 @@ def bench_infer(args):
     import torch
     from ranklib_amd import _native as N
     from ranklib_amd import synth
-    torch.cuda.set_device(0)
+    # N > 1 (torch.distributed.run): independent replicas, every rank scores its own `--docs` rows with the same model ("scaling": "weak";
+    # there is nothing to exchange in Ensemble.eval).  gloo only carries the barrier and the max of the elapsed times.
+    world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+    torch.cuda.set_device(local_rank)
     F, L = 136, 31
     X, lab, qoff = synth.make_dataset(200000, F, "mslr")
-    g = N.Trainer(n_trees=args.infer_train_rounds, n_leaves=L)
+    g = N.Trainer(n_trees=args.infer_train_rounds, n_leaves=L, device=local_rank)
     g.set_train(X, lab, qoff)
     g.init()
     g.boost_rounds_async(args.infer_train_rounds)
@@ -100,14 +107,14 @@ def bench_infer(args):
                 tiled.append(b.split(">", 1)[1])        # drop the <tree id=.. weight=..> opening, re-numbered below
     text = head + "<ensemble>\n" + "".join("\t<tree id=\"%d\" weight=\"0.1\">%s\t</tree>\n" % (i + 1, t) for i, t in enumerate(tiled)) + "</ensemble>\n"
     t0 = time.time()
-    m = N.Model(text)
+    m = N.Model(text, device=local_rank)
     t_load = time.time() - t0
     nt = m.num_trees()
     # mean path length on the training distribution from the per-node training counts
     visits = float(np.mean([t["count"][t["feature"] != -1].sum() / t["count"][0] for t in trees]))
     n = args.docs
     stride = F + 1
-    gen = torch.Generator(device="cuda").manual_seed(20240601)
+    gen = torch.Generator(device="cuda").manual_seed(20240601 + rank)
     dX = torch.empty((n, stride), dtype=torch.float32, device="cuda")
     chunk = 1 << 20
     for a in range(0, n, chunk):
@@ -124,6 +131,8 @@ def bench_infer(args):
     for _ in range(args.warmup):
         m.predict_device(dX.data_ptr(), n, stride, dO.data_ptr())
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
@@ -131,16 +140,24 @@ def bench_infer(args):
         m.predict_device(dX.data_ptr(), n, stride, dO.data_ptr())
     e1.record()
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
     elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
     ms = e0.elapsed_time(e1) / args.steps
-    docs_per_s = n * args.steps / elapsed
+    docs_per_s = n * world * args.steps / elapsed
+    if rank != 0:
+        return
     out = {
         "metric": "documents scored/sec (Ensemble.eval, %d trees x %d leaves)" % (nt, L), "value": docs_per_s, "unit": "docs/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 compares, f32 score chain (as Ensemble.eval)",
         "data": "synthetic",
-        "config": {"workload": "c4-shape inference: %d documents x %d features resident in HBM, %d trees (%d trained rounds tiled), "
-                               "31 leaves" % (n, F, nt, args.infer_train_rounds),
+        "config": {"workload": "c4 (BASELINE.json configs[4]) inference: %d documents x %d features per GPU resident in HBM, %d GPU(s) as independent replicas, "
+                               "%d trees (%d trained rounds tiled), 31 leaves" % (n, F, world, nt, args.infer_train_rounds),
                    "mean_node_visits_per_tree": visits, "node_visits_per_s": docs_per_s * nt * visits,
                    "model_parse_seconds": round(t_load, 2)},
         "roofline": {"kernel": "rl::k_model_eval_tiled", "bound": "hbm", "achieved": n * stride * 4.0 / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
@@ -186,7 +203,7 @@ def main():
     ap.add_argument("--java-order", action="store_true", help="RL_FLAG_JAVA_ORDER: the strict mode (split gains from the Java's own f64 summation order)")
     ap.add_argument("--workload", default="train", help="train (default, the BASELINE.json metric) | infer (configs[4]: Ensemble.eval)")
     ap.add_argument("--trees", type=int, default=10000, help="infer: trees in the scored model")
-    ap.add_argument("--docs", type=int, default=10000000, help="infer: rows per step (54.8 GB at the 100 M of configs[4])")
+    ap.add_argument("--docs", type=int, default=100000000, help="infer: rows per GPU and step (configs[4]: 100 M = 54.8 GB of rows in HBM)")
     ap.add_argument("--infer-train-rounds", type=int, default=100)
     args = ap.parse_args()
     if args.plain:

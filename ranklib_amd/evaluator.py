@@ -168,6 +168,7 @@ def main(argv=None):
         elif a == "-score": scoreFile = nxt()
         elif a == "-indri": indriRankingFile = nxt()
         elif a == "-missingzero": DataPoint.missingZero = True
+        elif a == "-cache": FeatureManager.cache = True      # not a RankLib flag: binary cache of the parsed LETOR files (features.py)
         elif a == "-sparse": pass                           # row storage only (:268-269)
         elif a == "-tree": LambdaMART.nTrees = RFRanker.nTrees = int(nxt())                 # :326-337: both sets of statics
         elif a == "-leaf": LambdaMART.nTreeLeaves = RFRanker.nTreeLeaves = int(nxt())

@@ -2,6 +2,9 @@
 getFeatureFromSampleVector :303-322) and utilities/FileUtils.smartReader (.gz by extension)."""
 import gzip
 import logging
+import os
+
+import numpy as np
 
 from ._native import RankLibError
 from .learning import DataPoint, RankList
@@ -63,6 +66,9 @@ class FeatureManager:
             N.lib()
         except Exception:             # noqa: BLE001 -- no library (e.g. a CPU-only checkout): the Python reader still works
             return None
+        cached = FeatureManager._cache_load(inputFile) if FeatureManager.cache else None
+        if cached is not None:
+            return FeatureManager._lists_from_arrays(cached, mustHaveRelDoc)
         raw = (gzip.open(inputFile, "rb") if inputFile.endswith(".gz") else open(inputFile, "rb")).read()
         try:
             raw.decode("ascii")
@@ -77,6 +83,10 @@ class FeatureManager:
         qe = (p["qid_off"] + p["qid_len"]).tolist()
         de = (p["desc_off"] + p["desc_len"]).tolist()
         le = (p["line_off"] + p["line_len"]).tolist()
+        if FeatureManager.cache and not any(slow):
+            FeatureManager._cache_save(inputFile, dict(
+                X=X, labels=p["labels"], last_fid=p["last_fid"], max_fid=np.int32(mf),
+                qids=np.array([text[qo[i]:qe[i]] for i in range(n)], dtype="S"), descs=np.array([text[do[i]:de[i]] for i in range(n)], dtype="S")))
         from_parsed = DataPoint.from_parsed
         samples, rl, lastID, hasRel = [], [], "", False
         for i in range(n):
@@ -96,6 +106,58 @@ class FeatureManager:
         if rl and (not mustHaveRelDoc or hasRel):
             samples.append(RankList(rl))
         return samples, n
+
+    # ---- binary cache of a parsed LETOR file (the text of an MSLR-WEB30K fold is 5 GB) -------------------------------
+    # `<file>.rlcache.npz` next to the text: the dense row matrix, labels, largest feature id per line, qid and description strings.
+    # Written after a native parse without irregular lines, used when it is newer than the text.  Off by default (the reference has
+    # no such file); `python -m ranklib_amd.evaluator -cache ...` or FeatureManager.cache = True turn it on.
+    cache = False
+
+    @staticmethod
+    def _cache_path(inputFile):
+        return inputFile + ".rlcache.npz"
+
+    @staticmethod
+    def _cache_save(inputFile, arrays):
+        try:
+            tmp = FeatureManager._cache_path(inputFile) + ".tmp.npz"
+            np.savez(tmp, **arrays)
+            os.replace(tmp, FeatureManager._cache_path(inputFile))
+        except OSError as ex:          # read-only directory: the cache is an optimisation
+            logger.info("no LETOR cache written: %s", ex)
+
+    @staticmethod
+    def _cache_load(inputFile):
+        path = FeatureManager._cache_path(inputFile)
+        try:
+            if os.path.getmtime(path) < os.path.getmtime(inputFile):
+                return None
+            with np.load(path) as z:
+                return {k: z[k] for k in ("X", "labels", "last_fid", "max_fid", "qids", "descs")}
+        except (OSError, KeyError, ValueError):
+            return None
+
+    @staticmethod
+    def _lists_from_arrays(a, mustHaveRelDoc):
+        X, mf = a["X"], int(a["max_fid"])
+        rows, labels, last = list(X), a["labels"].tolist(), a["last_fid"].tolist()
+        qids, descs = [q.decode("ascii") for q in a["qids"]], [d.decode("ascii") for d in a["descs"]]
+        from_parsed = DataPoint.from_parsed
+        samples, rl, lastID, hasRel = [], [], "", False
+        for i in range(len(labels)):
+            row = rows[i]
+            qp = from_parsed(labels[i], qids[i], descs[i], row if last[i] == mf else row[:last[i] + 1])
+            if lastID and lastID != qp.id:
+                if not mustHaveRelDoc or hasRel:
+                    samples.append(RankList(rl))
+                rl, hasRel = [], False
+            if qp.label > 0:
+                hasRel = True
+            lastID = qp.id
+            rl.append(qp)
+        if rl and (not mustHaveRelDoc or hasRel):
+            samples.append(RankList(rl))
+        return samples, len(labels)
 
     @staticmethod
     def readFeature(featureDefFile):

@@ -737,3 +737,28 @@ def test_unlimited_leaves(mls, n_docs, strict):
         assert np.array_equal(g.array("SCORE").view(np.int64), o.scores().view(np.int64)), r
         assert tmo == tmg, r
     assert "## No. of leaves = -1" in g.model_text()
+
+
+def test_ensemble_eval_with_1200_trees_streams_many_lds_tiles():
+    """configs[4] in small: a model of 1200 trees (40 trained rounds tiled 30 x, as bench.py --workload infer builds its 10 000) is scored
+    through ~38 LDS tiles of 32 trees per block; Ensemble.eval's float accumulation in tree order must survive the tile boundaries
+    (learning/tree/Ensemble.java:110-116): scores equal the oracle's flat evaluation of the same trees, bit for bit."""
+    X, lab, qoff = make(4000, 24, "mslr", 61)
+    g = N.Trainer(n_trees=40, n_leaves=31)
+    g.set_train(X, lab, qoff); g.init()
+    g.boost_rounds_async(40); g.sync(); g.finish()
+    trees = [g.get_tree(i).trimmed() for i in range(40)]
+    text = g.model_text()
+    head, body = text.split("<ensemble>\n", 1)
+    blocks = body.rsplit("</ensemble>", 1)[0].split("\t</tree>\n")[:-1]
+    tiled = [b.split(">", 1)[1] for _ in range(30) for b in blocks]
+    text = head + "<ensemble>\n" + "".join("\t<tree id=\"%d\" weight=\"0.1\">%s\t</tree>\n" % (i + 1, t) for i, t in enumerate(tiled)) + "</ensemble>\n"
+    m = N.Model(text)
+    assert m.num_trees() == 1200
+    n = 3001                                         # partial last document tile
+    rows = np.zeros((n, 25), np.float32)
+    rows[:, 1:] = X[:n]
+    got = m.predict_rows(rows)
+    want = O.eval_flat_model([trees[i % 40] for i in range(1200)], rows, n_threads=8)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    m.close()

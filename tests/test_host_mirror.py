@@ -351,3 +351,35 @@ def test_java_double_str_follows_double_toString():
     assert [j(v) for v in (5e-4, 1e-5, 0.001, 0.4000000059604645, 12345678.0, 9999999.0, 1e7, 123.0, -0.0, 0.0, 1.5e-10, 3.0e22, -2.5e-7)] == \
         ["5.0E-4", "1.0E-5", "0.001", "0.4000000059604645", "1.2345678E7", "9999999.0", "1.0E7", "123.0", "-0.0", "0.0", "1.5E-10", "3.0E22", "-2.5E-7"]
     assert j(float("nan")) == "NaN" and j(float("inf")) == "Infinity" and j(float("-inf")) == "-Infinity"
+
+
+def test_binary_cache_of_a_parsed_letor_file(tmp_path):
+    """FeatureManager.cache: `<file>.rlcache.npz` gives back the same ranked lists as the text (rows, labels, qids, descriptions),
+    is ignored once the text is newer, and is never written for files with irregular lines"""
+    import os
+    import time
+    from ranklib_amd.features import FeatureManager
+    p = str(tmp_path / "d.txt")
+    with open(p, "w") as f:
+        for q in range(7):
+            for d in range(3 + q):
+                f.write("%d qid:q%d 1:%s 2:%d 4:0.25 # doc %d-%d\n" % ((q + d) % 3, q, repr(0.1 * d + q), d, q, d))
+    try:
+        FeatureManager.cache = True
+        a = FeatureManager.readInput(p)
+        assert os.path.exists(p + ".rlcache.npz")
+        b = FeatureManager.readInput(p)                  # from the cache
+        assert len(a) == len(b) == 7
+        for x, y in zip(a, b):
+            assert x.getID() == y.getID() and x.size() == y.size()
+            for i in range(x.size()):
+                assert x.get(i).getLabel() == y.get(i).getLabel() and x.get(i).getDescription() == y.get(i).getDescription()
+                assert [x.get(i).getFeatureValue(f) for f in (1, 2, 3, 4)] == [y.get(i).getFeatureValue(f) for f in (1, 2, 3, 4)]
+        time.sleep(0.05)
+        with open(p, "a") as f:
+            f.write("2 qid:q9 1:5 2:5 4:5 # late\n")
+        os.utime(p, (time.time() + 5, time.time() + 5))
+        c = FeatureManager.readInput(p)                  # the text is newer: parsed again
+        assert len(c) == 8
+    finally:
+        FeatureManager.cache = False
