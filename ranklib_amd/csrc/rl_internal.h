@@ -165,6 +165,7 @@ struct Ctx {
     double *jbin;            // [kSpec][F][TS] per-bin Java-order sums of each slot's LEFT child (slot 0: the root pass)
     double *jtot;            // [kSpec][2]  sumResponse, sqSumResponse of the same nodes (FeatureHistogram.java:133-137,182-186)
     double *jcum;            // [NC][F][TS] cumulative Java-order sums of every live node
+    const uint16_t *jmap, *jinv; const uint32_t *jone;      // k_jhist2: bin -> owning (wavefront, lane), its inverse, single-bin wavefronts (null: k_jhist)
     long long *clk;          // [64][16] wall-clock stamps (10 ns units) of the finish / select phases of the last 64 growth steps; only
                              // written by builds with -DRL_PHASE_CLOCKS (tools/phase_clocks.py), RL_ARR_PHASE_CLOCKS reads it
 };

@@ -489,7 +489,8 @@ static int enqueue_round(rl_trainer *t)
         hipLaunchKernelGGL((k_hist_finish<true, true>), dim3(c.F), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
     } else if (c.java) {
         hipLaunchKernelGGL(k_jgather, dim3((c.N + kPartTile - 1) / kPartTile), dim3(kThreads), 0, s, c, 1);
-        hipLaunchKernelGGL(k_jhist, dim3(c.n_live, jbg + 2, 1), dim3(64), 0, s, c, 1, jbg);
+        if (c.jmap) hipLaunchKernelGGL(k_jhist2, dim3(c.n_live + 1, 1), dim3(kJ2Threads), 0, s, c, 1, c.jmap, c.jinv, c.jone);
+        else hipLaunchKernelGGL(k_jhist, dim3(c.n_live, jbg + 2, 1), dim3(64), 0, s, c, 1, jbg);
         hipLaunchKernelGGL((k_hist_finish<true, false, true>), dim3(c.n_live), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
     } else hipLaunchKernelGGL((k_hist_finish<true, false>), dim3(c.n_live), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
     // Growth steps: each prepares up to kSpec queue nodes and commits as many splits as the fit loop allows; L-1 steps
@@ -562,7 +563,8 @@ static int enqueue_round(rl_trainer *t)
             }
         } else if (c.java) {
             hipLaunchKernelGGL(k_jgather, dim3(c.nTiles), dim3(kThreads), 0, s, c, 0);
-            hipLaunchKernelGGL(k_jhist, dim3(c.n_live, jbg + 2, kSpec), dim3(64), 0, s, c, 0, jbg);
+            if (c.jmap) hipLaunchKernelGGL(k_jhist2, dim3(c.n_live + 1, kSpec), dim3(kJ2Threads), 0, s, c, 0, c.jmap, c.jinv, c.jone);
+            else hipLaunchKernelGGL(k_jhist, dim3(c.n_live, jbg + 2, kSpec), dim3(64), 0, s, c, 0, jbg);
             hipLaunchKernelGGL((k_hist_finish<false, false, true>), dim3(c.n_live, kSpec), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
         } else hipLaunchKernelGGL((k_hist_finish<false, false>), dim3(c.n_live, kSpec), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
     }
@@ -1078,6 +1080,43 @@ int rl_init(rl_trainer *t)
                 }
             }
         }
+    }
+
+    if (c.java && TS <= kJ2MaxBins && !getenv("RLHIP_JHIST_V1")) {
+        // k_jhist2's deal of a feature's bins to the 8 wavefronts of its block: consecutive bins until a wavefront owns about an
+        // eighth of the documents (root counts) or 64 bins; a bin that fills a share on its own keeps the wavefront to itself
+        std::vector<int32_t> h_cnt((size_t)F * TS);
+        RL_HIP(hipMemcpy(h_cnt.data(), c.cum_cnt, h_cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        std::vector<uint16_t> jmap((size_t)F * TS, 0), jinv((size_t)F * kJ2MaxBins, 0xffffu);
+        std::vector<uint32_t> jone(F, 0);
+        for (int f = 0; f < F; f++) {
+            const int T = h_nthr[f];
+            // a wavefront's quota = (documents not dealt yet) / (wavefronts left), taken when it starts; a bin joins the current wavefront
+            // while that brings it closer to its quota.  A wavefront that owns ONE bin adds without an owner test (8 cycles a sample
+            // against ~20): a bin that fills more than 40 % of a quota-sized share on its own is therefore kept alone.
+            int w = 0, used = 0, wbins[kJ2Waves] = {0};
+            int64_t docs = 0, left = N, quota = std::max<int64_t>(1, (int64_t)N / kJ2Waves);
+            for (int tb = 0; tb < T; tb++) {
+                const int64_t nb = (int64_t)h_cnt[(size_t)f * TS + tb] - (tb > 0 ? h_cnt[(size_t)f * TS + tb - 1] : 0);
+                const bool room_later = (T - tb) <= (kJ2Waves - w - 1) * 64;          // the wavefronts after this one can still hold all remaining bins
+                const bool alone = nb * 5 > quota * 2;
+                const bool full = used == 64 || docs + nb / 2 > quota || alone || (used == 1 && docs * 5 > quota * 2);
+                if (w < kJ2Waves - 1 && used > 0 && room_later && full) {
+                    w++; used = 0; left -= docs; docs = 0;
+                    quota = std::max<int64_t>(1, left / (kJ2Waves - w));
+                }
+                jmap[(size_t)f * TS + tb] = (uint16_t)((w << 8) | used);
+                jinv[(size_t)f * kJ2MaxBins + w * 64 + used] = (uint16_t)tb;
+                used++; docs += nb; wbins[w]++;
+            }
+            for (int v = 0; v < kJ2Waves; v++) if (wbins[v] == 1) jone[f] |= 1u << v;
+        }
+        uint16_t *d_map = nullptr, *d_inv = nullptr; uint32_t *d_one = nullptr;
+        RL_HIP(t->pool.alloc(&d_map, jmap.size())); RL_HIP(t->pool.alloc(&d_inv, jinv.size())); RL_HIP(t->pool.alloc(&d_one, jone.size()));
+        RL_HIP(hipMemcpy(d_map, jmap.data(), jmap.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        RL_HIP(hipMemcpy(d_inv, jinv.data(), jinv.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        RL_HIP(hipMemcpy(d_one, jone.data(), jone.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c.jmap = d_map; c.jinv = d_inv; c.jone = d_one;
     }
 
     // ---- query side: ideal DCGs with the qid-keyed cache quirk (NDCGScorer.java:114-122,134-143) --
