@@ -36,6 +36,9 @@ public class LambdaMART extends Ranker {
     public static int nTreeLeaves = 10;
     public static int minLeafSupport = 1;
     public static int device = 0;
+    /** RL_FLAG_JAVA_ORDER (rlhip.h): split gains from the f64 histogram the reference itself would hold, so that stored (feature,
+     *  threshold) pairs equal the reference's even where exact arithmetic ties.  Several times slower; one GPU only. */
+    public static boolean javaOrder = Boolean.getBoolean("rlhip.javaOrder");
     /** Feature sampling (FeatureHistogram.samplingRate < 1, set by RFRanker.init) draws through a seeded hash instead of the
      *  reference's unseeded java.util.Random: every trainer takes the next seed of this sequence (rlhip.h rl_params.seed). */
     public static long seed = System.nanoTime();
@@ -93,7 +96,7 @@ public class LambdaMART extends Ranker {
         final int metric = "NDCG".equals(mname) ? 0 : "DCG".equals(mname) ? 1 : "MAP".equals(mname) ? 2 : "ERR".equals(mname) ? 3 : -1;
         if (metric < 0) throw RankLibError.create("rlhip: the train metric must be NDCG, DCG, MAP or ERR (got " + scorer.name() + ")");
         handle = RlHipNative.create(nTrees, nTreeLeaves, nThreshold, minLeafSupport, nRoundToStopEarly, learningRate, metric, scorer.getK(),
-                rankerId(), device, FeatureHistogram.samplingRate, seed++);
+                rankerId(), device, FeatureHistogram.samplingRate, seed++, javaOrder ? 16 : 0);
         impacts = new double[features.length];
         try {
             final Map<String, Integer> qids = new HashMap<>();

@@ -6,9 +6,9 @@ import java.nio.FloatBuffer;
 final class RlHipNative {
     static { System.loadLibrary("rlhipjni"); }
     private RlHipNative() {}
-    /** metric: 0 NDCG, 1 DCG, 2 MAP, 3 ERR (RL_METRIC_*); ranker: 6 LambdaMART, 0 MART (RL_RANKER_*) */
+    /** metric: 0 NDCG, 1 DCG, 2 MAP, 3 ERR (RL_METRIC_*); ranker: 6 LambdaMART, 0 MART (RL_RANKER_*); flags: RL_FLAG_* (16 = RL_FLAG_JAVA_ORDER) */
     static native long create(int nTrees, int nLeaves, int nThreshold, int minLeafSupport, int stopEarly, float lr, int metric, int k,
-            int ranker, int device, float featureSamplingRate, long seed);
+            int ranker, int device, float featureSamplingRate, long seed, int flags);
     static native void destroy(long h);
     static native int setData(long h, boolean validation, FloatBuffer X, long nDocs, int nFeatures, float[] labels, int[] qoff,
             int[] featureIds, int[] qkey);

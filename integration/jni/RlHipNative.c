@@ -22,17 +22,17 @@ static void rl_throw(JNIEnv *env)
 #define CHECK(rc) do { if ((rc) != RL_OK) { rl_throw(env); return 0; } } while (0)
 
 /* long create(int nTrees, int nLeaves, int nThreshold, int minLeafSupport, int stopEarly, float lr, int metric, int k,
- *             int ranker, int device, float featureSamplingRate, long seed)
+ *             int ranker, int device, float featureSamplingRate, long seed, int flags)
  * metric: RL_METRIC_*, ranker: RL_RANKER_* (include/rlhip.h); featureSamplingRate = FeatureHistogram.samplingRate (set by RFRanker.init) */
 JNIEXPORT jlong JNICALL Java_ciir_umass_edu_learning_tree_RlHipNative_create(JNIEnv *env, jclass c, jint nTrees, jint nLeaves,
         jint nThreshold, jint mls, jint stopEarly, jfloat lr, jint metric, jint k, jint ranker, jint device,
-        jfloat featureSamplingRate, jlong seed)
+        jfloat featureSamplingRate, jlong seed, jint flags)
 {
     rl_params p; rl_trainer *t = NULL;
     rl_params_default(&p);
     p.n_trees = nTrees; p.n_leaves = nLeaves; p.n_threshold = nThreshold; p.min_leaf_support = mls;
     p.early_stop_rounds = stopEarly; p.learning_rate = lr; p.metric = metric; p.metric_k = k; p.ranker = ranker; p.device = device;
-    p.feature_sampling_rate = featureSamplingRate; p.seed = (uint64_t)seed;
+    p.feature_sampling_rate = featureSamplingRate; p.seed = (uint64_t)seed; p.flags = flags;
     CHECK(rl_create(&p, &t));
     return (jlong)(intptr_t)t;
 }
