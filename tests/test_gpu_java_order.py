@@ -137,3 +137,22 @@ def test_flag_is_rejected_with_sharding():
     g.dist_init_callback(0, 1, lambda arr, op: None, lambda src: src.copy())
     with pytest.raises(N.RankLibError):
         g.init()
+
+
+def test_first_version_kernel_and_wide_threshold_tables(monkeypatch):
+    """k_jhist (one wavefront per 64 bins, scalar-load walk) still serves threshold tables beyond k_jhist2's 512 bins: -tc -1 on a
+    column with ~1500 distinct values takes it by itself; RLHIP_JHIST_V1 forces it on an ordinary table.  Same trees either way."""
+    X, lab, qoff = make(3000, 6, "ns", 17)
+    X = X.copy()
+    X[:, 1] = np.round(X[:, 1] * 1500) / 1500            # ~1500 distinct values: 1501 bins with -tc -1
+    for tc, force in ((-1, False), (256, True)):
+        if force:
+            monkeypatch.setenv("RLHIP_JHIST_V1", "1")
+        o, g = pair(X, lab, qoff, n_trees=3, n_leaves=9, n_threshold=tc)
+        o.init(); g.init()
+        assert (g.array("NBINS").max() > 512) == (tc == -1)
+        for r in range(3):
+            to, tmo, _, _ = o.round()
+            tg, tmg, _, _ = g.boost_round()
+            same_tree(to, tg, X, "tc %d round %d" % (tc, r))
+            assert tmo == tmg
