@@ -113,6 +113,7 @@ struct Ctx {
     const uint16_t *dbins;  // [Npad][numFG][kHistFG]  document-major: ALL groups of a document adjacent (numFG x 32 bytes).  A sparse node's
                             // sample list touches one 128-byte memory line per (document, group) in gbins -- 4 x the bytes it uses -- but only
                             // the document's own ~numFG/4 lines here; the feature-group blocks of one chunk run on one XCD and share them in L2
+    int32_t dm_gstride;        // groups per document row of dbins: numFG rounded up to a multiple of 4 (rows start on 128-byte lines)
     int32_t dm_root, dm_div;   // document-major rows for the root pass (0 / 1); for a node of cnt samples when cnt * dm_div <= N (0 = never, 1 = every child)
     int32_t sub;            // features of a group handled per histogram block (kHistFG unless the threshold table is huge)
     const int32_t *mode;    // [F] most populated bin of every feature: never accumulated, rebuilt as total - others

@@ -1017,8 +1017,10 @@ int rl_init(rl_trainer *t)
     if (t->dist) { int rcd = t->dist->allreduce(c.cum_cnt, (size_t)F * TS, DT_I32, OP_SUM, s); if (rcd) return rcd; }
     {
         uint16_t *d_dbins = nullptr;
-        RL_HIP(t->pool.alloc(&d_dbins, (size_t)c.numFG * Npad * kHistFG));
-        hipLaunchKernelGGL(k_docmajor, dim3(4096), dim3(kThreads), 0, s, (const uint16_t *)d_gbins, d_dbins, Npad, c.numFG);
+        c.dm_gstride = getenv("RLHIP_DM_NOALIGN") ? c.numFG : (c.numFG + 3) & ~3;
+        RL_HIP(t->pool.alloc(&d_dbins, (size_t)c.dm_gstride * Npad * kHistFG));
+        RL_HIP(hipMemsetAsync(d_dbins, 0, (size_t)c.dm_gstride * Npad * kHistFG * sizeof(uint16_t), s));
+        hipLaunchKernelGGL(k_docmajor, dim3(4096), dim3(kThreads), 0, s, (const uint16_t *)d_gbins, d_dbins, Npad, c.numFG, c.dm_gstride);
         c.dbins = d_dbins;
         c.dm_root = 0; c.dm_div = 1;      // measured at c2 (profiles/r02d_dm_sweep.txt): every child pass gains, the root pass loses
         if (const char *e = getenv("RLHIP_DM_ROOT")) c.dm_root = atoi(e) ? 1 : 0;      // tuning knobs (tools/), not API
