@@ -250,9 +250,16 @@ def main():
     t0 = time.time()
     g.set_train(X, lab, qoff)
     if world > 1:
-        box = [g.dist_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        g.dist_init(box[0], rank, world)
+        if os.environ.get("RLHIP_BENCH_TRANSPORT") == "gloo":
+            # test aid (with RLHIP_BENCH_SAME_GPU): the host-callback transport lets several ranks share the one GPU of a test box, where
+            # RCCL refuses duplicate devices -- exercises this script's N > 1 path, not the interconnect
+            from ranklib_amd import dist as D
+            tr = D.TorchHostTransport()
+            g.dist_init_callback(rank, world, tr.allreduce, tr.allgather)
+        else:
+            box = [g.dist_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            g.dist_init(box[0], rank, world)
     g.init()
     t_init = time.time() - t0
 
