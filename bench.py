@@ -56,7 +56,7 @@ def live_pmc(shape, rounds=4):
             d = tempfile.mkdtemp(prefix="rlhip_pmc_", dir="/tmp")
             cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "bench.py"),
                    "--shape", shape, "--steps", str(rounds - 1), "--warmup", "1", "--plain"]
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=420, check=True)
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
             con = sqlite3.connect(glob.glob(os.path.join(d, "**", "*.db"), recursive=True)[0])
             for name, n, tot in con.execute("select kernel_name, count(*), sum(value) from counters_collection where counter_name=? group by kernel_name", (ctr,)):
                 if "k_hist<true" in name:
