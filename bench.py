@@ -56,7 +56,16 @@ def live_pmc(shape, rounds=4):
             d = tempfile.mkdtemp(prefix="rlhip_pmc_", dir="/tmp")
             cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "bench.py"),
                    "--shape", shape, "--steps", str(rounds - 1), "--warmup", "1", "--plain"]
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
+            # its own process group: on a timeout the profiler AND the benchmark under it are killed (by exact pgid)
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                if pr.wait(timeout=150) != 0:
+                    raise RuntimeError("rocprofv3 exited with %d" % pr.returncode)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(pr.pid, signal.SIGKILL)
+                pr.wait()
+                raise
             con = sqlite3.connect(glob.glob(os.path.join(d, "**", "*.db"), recursive=True)[0])
             for name, n, tot in con.execute("select kernel_name, count(*), sum(value) from counters_collection where counter_name=? group by kernel_name", (ctr,)):
                 if "k_hist<true" in name:
