@@ -18,6 +18,8 @@ logger = logging.getLogger("ranklib_amd")
 
 
 class Evaluator:
+    mustHaveRelDoc = False            # the reference's static of the same name (eval/Evaluator.java:551), set by -hr
+
     def __init__(self, rType, trainMetric, testMetric):
         self.type = rType
         mf = MetricScorerFactory()
@@ -26,9 +28,9 @@ class Evaluator:
         self.rFact = RankerFactory()
 
     def evaluate(self, trainFile, validationFile=None, testFile=None, featureDefFile=None, modelFile=None):   # :669-708
-        train = FeatureManager.readInput(trainFile)
-        validation = FeatureManager.readInput(validationFile) if validationFile else None
-        test = FeatureManager.readInput(testFile) if testFile else None
+        train = _read_input(trainFile)
+        validation = _read_input(validationFile) if validationFile else None
+        test = _read_input(testFile) if testFile else None
         features = FeatureManager.readFeature(featureDefFile) if featureDefFile else FeatureManager.getFeatureFromSampleVector(train)
         trainer = RankerTrainer()
         if validation is not None:
@@ -54,10 +56,10 @@ class Evaluator:
         return trainer.train(self.type, train, features, self.trainScorer)
 
     def evaluate_tts(self, sampleFile, validationFile, featureDefFile, percentTrain, modelFile=None):     # -tts  :716-739
-        samples = FeatureManager.readInput(sampleFile)
+        samples = _read_input(sampleFile)
         features = self._features(featureDefFile, samples)
         train, test = FeatureManager.prepareSplit(samples, percentTrain)
-        validation = FeatureManager.readInput(validationFile) if validationFile else None
+        validation = _read_input(validationFile) if validationFile else None
         ranker = self._train(train, validation, features)
         s = self.testScorer.score(ranker.rank(test))
         logger.info("%s on test data: %s", self.testScorer.name(), java_round(s, 4))
@@ -67,10 +69,10 @@ class Evaluator:
         return ranker, s
 
     def evaluate_tvs(self, trainFile, percentTrain, testFile, featureDefFile, modelFile=None):            # -tvs  :749-773
-        samples = FeatureManager.readInput(trainFile)
+        samples = _read_input(trainFile)
         features = self._features(featureDefFile, samples)
         train, validation = FeatureManager.prepareSplit(samples, percentTrain)
-        test = FeatureManager.readInput(testFile) if testFile else None
+        test = _read_input(testFile) if testFile else None
         ranker = self._train(train, validation, features)
         s = None
         if test is not None:
@@ -82,7 +84,7 @@ class Evaluator:
         return ranker, s
 
     def evaluate_kcv(self, sampleFile, featureDefFile, nFold, tvs=-1.0, modelDir="", modelFile=""):      # -kcv  :798-873
-        samples = FeatureManager.readInput(sampleFile)
+        samples = _read_input(sampleFile)
         features = self._features(featureDefFile, samples)
         trainingData, validationData, testData = FeatureManager.prepareCV(samples, nFold, tvs)
         scores, scoreOnTrain, scoreOnTest, totalScoreOnTest, totalTestSampleSize = [], 0.0, 0.0, 0.0, 0
@@ -109,7 +111,7 @@ class Evaluator:
 
     def score(self, modelFile, testFile, outputFile):      # :1076-1094: qid \t index \t score
         ranker = self.rFact.loadRankerFromFile(modelFile)
-        test = FeatureManager.readInput(testFile)
+        test = _read_input(testFile)
         with open(outputFile, "w", encoding="utf-8") as out:
             for rl in test:
                 for j, v in enumerate(ranker.evalList(rl)):
@@ -117,7 +119,7 @@ class Evaluator:
 
     def rank(self, modelFile, testFile, indriFile):        # :1168-1194: qid Q0 docno rank score indri
         ranker = self.rFact.loadRankerFromFile(modelFile)
-        test = FeatureManager.readInput(testFile)
+        test = _read_input(testFile)
         with open(indriFile, "w", encoding="utf-8") as out:
             for rl in test:
                 sc = ranker.evalList(rl)
@@ -125,12 +127,32 @@ class Evaluator:
                     docno = rl.get(int(j)).getDescription().replace("#", "").strip()
                     out.write("%s Q0 %s %d %s indri\n" % (rl.getID(), docno, i + 1, java_double_str(java_round(float(sc[int(j)]), 5))))
 
-    def test(self, modelFile, testFile):                   # evaluate a saved model
+    def test(self, modelFile, testFile, prpFile=""):       # evaluate a saved model (:915-944); -idv: performance per ranked list
         ranker = self.rFact.loadRankerFromFile(modelFile)
-        test = FeatureManager.readInput(testFile)
-        s = self.testScorer.score(ranker.rank(test))
-        logger.info("%s on test data: %s", self.testScorer.name(), java_round(s, 4))
-        return s
+        test = _read_input(testFile)
+        ids, scores, rankScore = [], [], 0.0
+        for rl in test:
+            l = ranker.rank(rl)
+            sc = self.testScorer.score(l)
+            ids.append(l.getID()); scores.append(sc)
+            rankScore += sc
+        rankScore /= len(test)
+        ids.append("all"); scores.append(rankScore)
+        logger.info("%s on test data: %s", self.testScorer.name(), java_round(rankScore, 4))
+        if prpFile:
+            self.savePerRankListPerformanceFile(ids, scores, prpFile)
+            logger.info("Per-ranked list performance saved to: %s", prpFile)
+        return rankScore
+
+    def savePerRankListPerformanceFile(self, ids, scores, prpFile):       # :1343-1352: "<metric>   <qid>   <Double.toString(score)>"
+        with open(prpFile, "w", encoding="utf-8") as out:
+            for i, sc in zip(ids, scores):
+                out.write("%s   %s   %s\n" % (self.testScorer.name(), i, java_double_str(sc)))
+
+
+def _read_input(inputFile):
+    """Evaluator.readInput (eval/Evaluator.java:625-627): honours the static -hr switch"""
+    return FeatureManager.readInput(inputFile, Evaluator.mustHaveRelDoc)
 
 
 def main(argv=None):
@@ -140,7 +162,8 @@ def main(argv=None):
         print("Usage: -train <file> -ranker 6|0|8 [-bag n -srate f -frate f -rtype 0|6 -seed n] [-metric2t NDCG@k|DCG@k|MAP|ERR@k] [-tree n] [-leaf n] [-shrinkage f] [-tc n] [-mls n] [-estop n] "
               "[-validate f] [-test f] [-feature f] [-save model] | -load model [-test f] [-rank f -indri out] [-score out]")
         return 0
-    trainFile = validationFile = testFile = featureDescriptionFile = savedModelFile = rankFile = indriRankingFile = scoreFile = modelFile = ""
+    trainFile = validationFile = testFile = featureDescriptionFile = savedModelFile = rankFile = indriRankingFile = scoreFile = modelFile = prpFile = ""
+    Evaluator.mustHaveRelDoc = False
     rankerType = 4                                          # the reference's default is Coordinate Ascent (:83)
     trainMetric, testMetric = "ERR@10", ""                  # the reference's default train metric (:84)
     ttSplit = tvSplit = 0.0
@@ -170,6 +193,8 @@ def main(argv=None):
         elif a == "-missingzero": DataPoint.missingZero = True
         elif a == "-cache": FeatureManager.cache = True      # not a RankLib flag: binary cache of the parsed LETOR files (features.py)
         elif a == "-sparse": pass                           # row storage only (:268-269)
+        elif a == "-hr": Evaluator.mustHaveRelDoc = True    # :367-368: ranked lists without a relevant document are dropped by the reader
+        elif a == "-idv": prpFile = nxt()                   # :281-282
         elif a == "-tree": LambdaMART.nTrees = RFRanker.nTrees = int(nxt())                 # :326-337: both sets of statics
         elif a == "-leaf": LambdaMART.nTreeLeaves = RFRanker.nTreeLeaves = int(nxt())
         elif a == "-shrinkage": LambdaMART.learningRate = RFRanker.learningRate = float(nxt())
@@ -225,7 +250,7 @@ def main(argv=None):
         elif rankFile and scoreFile:
             e.score(savedModelFile, rankFile, scoreFile)
         elif testFile:
-            e.test(savedModelFile, testFile)
+            e.test(savedModelFile, testFile, prpFile)
     return 0
 
 

@@ -383,3 +383,54 @@ def test_binary_cache_of_a_parsed_letor_file(tmp_path):
         assert len(c) == 8
     finally:
         FeatureManager.cache = False
+
+
+def test_hr_drops_lists_without_a_relevant_document_and_idv_format(tmp_path):
+    """-hr (eval/Evaluator.java:367-368 -> FeatureManager.readInput mustHaveRelDoc, :230-233); the -idv line format
+    `<metric>   <qid>   <Double.toString(score)>` with the closing "all" line (:915-944, :1343-1352) checked on a hand-made model"""
+    from ranklib_amd import evaluator as E
+    from ranklib_amd.features import FeatureManager
+    p = str(tmp_path / "t.txt")
+    with open(p, "w") as f:
+        f.write("0 qid:a 1:1 2:0\n0 qid:a 1:0 2:1\n")          # no relevant document
+        f.write("2 qid:b 1:1 2:0\n0 qid:b 1:0 2:1\n1 qid:b 1:0.5 2:0.5\n")
+    assert len(FeatureManager.readInput(p)) == 2 and len(FeatureManager.readInput(p, True)) == 1
+    model = str(tmp_path / "m.txt")
+    with open(model, "w") as f:
+        f.write("## LambdaMART\n## No. of trees = 1\n## No. of leaves = 2\n## No. of threshold candidates = 256\n## Learning rate = 0.1\n## Stop early = 100\n\n"
+                "<ensemble>\n\t<tree id=\"1\" weight=\"0.1\">\n\t\t<split>\n\t\t\t<feature>1 </feature>\n\t\t\t<threshold> 0.25 </threshold>\n"
+                "\t\t\t<split pos=\"left\">\n\t\t\t\t<output>-1.0 </output>\n\t\t\t</split>\n\t\t\t<split pos=\"right\">\n\t\t\t\t<output>2.0 </output>\n\t\t\t</split>\n"
+                "\t\t</split>\n\t</tree>\n</ensemble>\n")
+    E.Evaluator.mustHaveRelDoc = True
+    try:
+        assert len(E._read_input(p)) == 1
+    finally:
+        E.Evaluator.mustHaveRelDoc = False
+
+
+@pytest.mark.gpu
+def test_cli_idv_and_hr_flow(tmp_path):
+    """`-load m -test f -idv out [-hr]` (eval/Evaluator.java:915-944,1343-1352): one `<metric>   <qid>   <score>` line per ranked list that
+    survives -hr, then the mean as `all`; scores printed as Double.toString does"""
+    p = str(tmp_path / "t.txt")
+    with open(p, "w") as f:
+        f.write("0 qid:a 1:1 2:0\n0 qid:a 1:0 2:1\n")          # no relevant document: dropped by -hr
+        f.write("2 qid:b 1:1 2:0\n0 qid:b 1:0 2:1\n1 qid:b 1:0.5 2:0.5\n")
+        f.write("0 qid:c 1:1 2:0\n1 qid:c 1:0 2:1\n")
+    model = str(tmp_path / "m.txt")
+    with open(model, "w") as f:
+        f.write("## LambdaMART\n## No. of trees = 1\n## No. of leaves = 2\n## No. of threshold candidates = 256\n## Learning rate = 0.1\n## Stop early = 100\n\n"
+                "<ensemble>\n\t<tree id=\"1\" weight=\"0.1\">\n\t\t<split>\n\t\t\t<feature>1 </feature>\n\t\t\t<threshold> 0.25 </threshold>\n"
+                "\t\t\t<split pos=\"left\">\n\t\t\t\t<output>-1.0 </output>\n\t\t\t</split>\n\t\t\t<split pos=\"right\">\n\t\t\t\t<output>2.0 </output>\n\t\t\t</split>\n"
+                "\t\t</split>\n\t</tree>\n</ensemble>\n")
+    out = str(tmp_path / "idv.txt")
+    evaluator.main(["-load", model, "-test", p, "-metric2T", "NDCG@10", "-idv", out])
+    rows = [l.split("   ") for l in open(out).read().splitlines()]
+    assert [r[1] for r in rows] == ["a", "b", "c", "all"] and all(r[0] == "NDCG@10" for r in rows)
+    # the model ranks feature-1 > 0.25 first: b = [2, 1, 0] (perfect), c = [0, 1]; a has no relevant document (NDCG 0)
+    assert rows[0][2] == "0.0" and rows[1][2] == "1.0"
+    c = (2 ** 1 - 1) / np.log2(3) / 1.0
+    assert abs(float(rows[2][2]) - c) < 1e-12 and abs(float(rows[3][2]) - (0.0 + 1.0 + c) / 3) < 1e-12
+    evaluator.main(["-load", model, "-test", p, "-metric2T", "NDCG@10", "-idv", out, "-hr"])
+    rows = [l.split("   ") for l in open(out).read().splitlines()]
+    assert [r[1] for r in rows] == ["b", "c", "all"] and abs(float(rows[2][2]) - (1.0 + c) / 2) < 1e-12
