@@ -54,3 +54,29 @@ def test_parameter_validation_messages():
     p.n_trees = 0
     assert L.rl_create(C.byref(p), C.byref(h)) == -1
     assert b"n_trees" in L.rl_last_error()
+
+
+def test_header_is_valid_c99_and_the_c_example_compiles(tmp_path):
+    """the boundary is a C ABI: rlhip.h must compile as plain C (no C++ types), and the example that drives the whole path from C
+    (integration/c/train_example.c) must compile against it; with a GPU it is also linked and run"""
+    import shutil
+    import subprocess
+    cc = shutil.which("gcc")
+    assert cc, "gcc is part of the image"
+    inc = os.path.join(ROOT, "include")
+    src = os.path.join(ROOT, "integration", "c", "train_example.c")
+    subprocess.check_call([cc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-x", "c", os.path.join(inc, "rlhip.h")])
+    subprocess.check_call([cc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, src])
+
+
+@pytest.mark.gpu
+def test_c_example_trains_through_the_abi(tmp_path):
+    import subprocess
+    _ensure_built()
+    exe = str(tmp_path / "train_example")
+    libdir = os.path.dirname(N.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "integration", "c", "train_example.c"),
+                           "-L", libdir, "-lrlhip", "-Wl,-rpath," + libdir, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "## LambdaMART" in out.stdout and "<ensemble>" in out.stdout and out.stdout.count("<tree id=") == 10
