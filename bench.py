@@ -209,6 +209,7 @@ def main():
     ap.add_argument("--node-rounds", type=int, default=10, help="extra rounds with HIP events around every child-node histogram launch (0 = skip)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--plain", action="store_true", help="timed region only: no CPU baseline, sustained run, node timing, membench or PMC passes")
+    ap.add_argument("--metric", default="NDCG", help="train metric: NDCG (the BASELINE.json metric) | DCG | ERR | MAP (RankLib's own default is ERR@10)")
     ap.add_argument("--java-order", action="store_true", help="RL_FLAG_JAVA_ORDER: the strict mode (split gains from the Java's own f64 summation order)")
     ap.add_argument("--workload", default="train", help="train (default, the BASELINE.json metric) | infer (configs[4]: Ensemble.eval)")
     ap.add_argument("--trees", type=int, default=10000, help="infer: trees in the scored model")
@@ -255,7 +256,8 @@ def main():
         flags |= N.RL_FLAG_JAVA_ORDER
         args.sustain = min(args.sustain, 20)
     total_rounds = args.warmup + args.steps
-    g = N.Trainer(n_trees=max(total_rounds + args.sustain + args.node_rounds, 1), n_leaves=n_leaves, device=local_rank, flags=flags)
+    g = N.Trainer(n_trees=max(total_rounds + args.sustain + args.node_rounds, 1), n_leaves=n_leaves, device=local_rank, flags=flags,
+                  metric=args.metric.upper(), metric_k=0 if args.metric.upper() == "MAP" else 10)
     t0 = time.time()
     g.set_train(X, lab, qoff)
     if world > 1:
@@ -327,7 +329,7 @@ def main():
         return
     rounds_per_s = args.steps / elapsed
     out = {
-        "metric": "boosting rounds/sec (LambdaMART -ranker 6, NDCG@10)",
+        "metric": "boosting rounds/sec (LambdaMART -ranker 6, %s)" % ("MAP" if args.metric.upper() == "MAP" else args.metric.upper() + "@10"),
         "value": rounds_per_s,
         "unit": "rounds/s",
         "n_gpus": world,
