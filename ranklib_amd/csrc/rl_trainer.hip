@@ -436,23 +436,30 @@ static int enqueue_round(rl_trainer *t)
                   t->d_T, c.lw, &c.st->maxabs_bits, c.N, c.k, c.k, c.metric, t->p.metric_k,
                   t->tr.d_aux_i, t->tr.d_aux_a, t->tr.d_aux_b, t->d_wmax};
         if (t->d_T == nullptr) {
-            auto lds_of = [&](int bt) { return (size_t)c.k * (bt + 8) * 16 + (size_t)c.k * 24; };
+            const int mode = (c.metric == RL_METRIC_ERR) ? 1 : (c.metric == RL_METRIC_MAP) ? 2 : 0;
+            auto lds_of = [&](int bt) { return (size_t)c.k * (bt + 8) * 16 + (size_t)c.k * 24 + lambda_fused_extra_bytes(mode, c.k, bt); };
             n_max = 0;
             const DataSet &d = t->tr;
-            if (d.n_qcls[4] > 0) {
+#define RL_LAUNCH_FUSED(BT, cls)                                                                                                             \
+            if (d.n_qcls[cls] > 0) {                                                                                                         \
+                if (mode == 0) hipLaunchKernelGGL((k_lambda_fused<BT, 0>), dim3(d.n_qcls[cls]), dim3(BT), lds_of(BT), s, g, (const int *)d.d_qcls[cls], d.n_qcls[cls]); \
+                else if (mode == 1) hipLaunchKernelGGL((k_lambda_fused<BT, 1>), dim3(d.n_qcls[cls]), dim3(BT), lds_of(BT), s, g, (const int *)d.d_qcls[cls], d.n_qcls[cls]); \
+                else hipLaunchKernelGGL((k_lambda_fused<BT, 2>), dim3(d.n_qcls[cls]), dim3(BT), lds_of(BT), s, g, (const int *)d.d_qcls[cls], d.n_qcls[cls]); \
+                n_max += d.n_qcls[cls]; g.blockmax = t->d_wmax + n_max;                                                                      \
+            }
+            if (d.n_qcls[4] > 0 && mode == 0) {
                 const int nb = (d.n_qcls[4] + kLambdaTinyGroups - 1) / kLambdaTinyGroups;
                 hipLaunchKernelGGL(k_lambda_tiny, dim3(nb), dim3(kLambdaTinyDocs * kLambdaTinyGroups),
                                    (size_t)kLambdaTinyGroups * lambda_tiny_group_bytes(c.k), s, g, (const int *)d.d_qcls[4], d.n_qcls[4]);
                 n_max += nb; g.blockmax = t->d_wmax + n_max;
+            } else {
+                RL_LAUNCH_FUSED(64, 4)          // ERR / MAP: the lists of at most 16 documents take the block-per-query kernel too
             }
-            if (d.n_qcls[0] > 0) hipLaunchKernelGGL(k_lambda_fused<64>, dim3(d.n_qcls[0]), dim3(64), lds_of(64), s, g, (const int *)d.d_qcls[0], d.n_qcls[0]);
-            n_max += d.n_qcls[0]; g.blockmax = t->d_wmax + n_max;
-            if (d.n_qcls[1] > 0) hipLaunchKernelGGL(k_lambda_fused<128>, dim3(d.n_qcls[1]), dim3(128), lds_of(128), s, g, (const int *)d.d_qcls[1], d.n_qcls[1]);
-            n_max += d.n_qcls[1]; g.blockmax = t->d_wmax + n_max;
-            if (d.n_qcls[2] > 0) hipLaunchKernelGGL(k_lambda_fused<192>, dim3(d.n_qcls[2]), dim3(192), lds_of(192), s, g, (const int *)d.d_qcls[2], d.n_qcls[2]);
-            n_max += d.n_qcls[2]; g.blockmax = t->d_wmax + n_max;
-            if (d.n_qcls[3] > 0) hipLaunchKernelGGL(k_lambda_fused<256>, dim3(d.n_qcls[3]), dim3(256), lds_of(256), s, g, (const int *)d.d_qcls[3], d.n_qcls[3]);
-            n_max += d.n_qcls[3];
+            RL_LAUNCH_FUSED(64, 0)
+            RL_LAUNCH_FUSED(128, 1)
+            RL_LAUNCH_FUSED(192, 2)
+            RL_LAUNCH_FUSED(256, 3)
+#undef RL_LAUNCH_FUSED
         } else {
             const unsigned nb = (unsigned)((c.N + kThreads - 1) / kThreads);
             hipLaunchKernelGGL(k_pair_terms, dim3(nb), dim3(kThreads), 0, s, g);
@@ -798,7 +805,9 @@ int rl_create(const rl_params *p, rl_trainer **out)
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     RL_HIP(hipFuncSetAttribute((const void *)k_rank_block, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaBlockCap * 12));
     RL_HIP(hipFuncSetAttribute((const void *)k_lambda_tiny, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaTinyGroups * lambda_tiny_group_bytes(kLambdaFusedMaxK)));
-    RL_HIP(hipFuncSetAttribute((const void *)k_lambda_fused<256>, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaFusedMaxK * (256 + 8) * 16 + 2048));
+    RL_HIP(hipFuncSetAttribute((const void *)k_lambda_fused<256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaFusedMaxK * (256 + 8) * 16 + 2048));
+    RL_HIP(hipFuncSetAttribute((const void *)k_lambda_fused<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaFusedMaxK * (256 + 8) * 16 + 8192));
+    RL_HIP(hipFuncSetAttribute((const void *)k_lambda_fused<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaFusedMaxK * (256 + 8) * 16 + 8192));
     RL_HIP(hipFuncSetAttribute((const void *)k_chain_stitch, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     *out = t.release();
     return RL_OK;
@@ -1282,8 +1291,8 @@ int rl_init(rl_trainer *t)
         std::vector<int32_t> docq((size_t)N);
         for (int q = 0; q < d.Q; q++) for (int i = d.qoff[q]; i < d.qoff[q + 1]; i++) docq[i] = q;
         RL_HIP(hipMemcpy(d.d_docq, docq.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice));
-        // the LDS-resident fused kernel serves NDCG / DCG with few rows; everything else goes through the pair-term matrix
-        const bool fused = !c.mart && (c.metric == RL_METRIC_NDCG || c.metric == RL_METRIC_DCG) && c.k <= kLambdaFusedMaxK;
+        // the LDS-resident fused kernel serves every metric with few rows (k <= kLambdaFusedMaxK); longer cutoffs go through the pair-term matrix
+        const bool fused = !c.mart && c.k <= kLambdaFusedMaxK && !getenv("RLHIP_LAMBDA_UNFUSED");
         if (!c.mart && !fused) {
             if ((size_t)N * c.k * sizeof(double2) > ((size_t)16 << 30)) return fail(RL_ERR_UNSUPPORTED, "this metric cutoff needs more than 16 GiB of pair terms");
             RL_HIP(t->pool.alloc(&t->d_T, (size_t)N * c.k));

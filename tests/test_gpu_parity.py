@@ -388,6 +388,45 @@ def test_lambda_kernel_variants_by_list_length_give_identical_lambdas(monkeypatc
             assert np.array_equal(rec[r][0], o.lambdas()) and np.array_equal(rec[r][1], o.weights()), "round %d" % r
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric,k", [("ERR", 10), ("ERR", 3), ("ERR", 16), ("ERR", 20), ("MAP", 0), ("MAP", 4), ("MAP", 15), ("MAP", 30), ("DCG", 5)])
+def test_fused_lambda_kernel_of_every_metric_on_mixed_list_lengths(metric, k, monkeypatch):
+    """the LDS-resident lambda kernel computes ERR's swap changes from a [size][size + 2] table per query and MAP's from one sequential
+    chain per row (k_lambda_fused MODE 1 / 2); cutoffs past kLambdaFusedMaxK (16; MAP visits k + 1 rows) and RLHIP_LAMBDA_UNFUSED take the
+    pair-term matrix.  Lists of 1 .. 700 documents (one to three tiles of the widest variant), lambdas / weights bit for bit against the
+    oracle over three rounds, and the two paths against each other."""
+    rng = np.random.default_rng(40 + k)
+    sizes = np.concatenate([rng.integers(1, 17, 200), rng.integers(17, 65, 60), rng.integers(65, 129, 30), rng.integers(129, 193, 12),
+                            rng.integers(193, 300, 8), [k, k + 1, k + 2, 16, 17, 64, 65, 256, 257, 512, 513, 700]])
+    sizes = sizes[sizes > 0]
+    rng.shuffle(sizes)
+    qoff = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    n = int(qoff[-1])
+    X = rng.random((n, 6)).astype(np.float32)
+    lab = np.floor(3 * X[:, 0] * X[:, 1] + 2 * rng.random(n)).astype(np.float32)
+    lab[qoff[5]:qoff[6]] = 0          # a list without a relevant document (MAP: rdCount == 0)
+    lab[qoff[7]:qoff[8]] = 2          # a list of equal labels
+    res = []
+    for unfused in (False, True):
+        if unfused:
+            monkeypatch.setenv("RLHIP_LAMBDA_UNFUSED", "1")
+        g = N.Trainer(n_trees=3, n_leaves=6, metric=metric, metric_k=k)
+        g.set_train(X, lab, qoff)
+        g.init()
+        rec = []
+        for _ in range(3):
+            _, tm, _, _ = g.boost_round()
+            rec.append((g.array("LAMBDA").copy(), g.array("WEIGHT").copy(), tm))
+        res.append(rec)
+    o = O.Oracle(X, lab, qoff, n_trees=3, n_leaves=6, metric=metric, k=k)
+    o.init()
+    for r in range(3):
+        _, tmo, _, _ = o.round()
+        for which, rec in enumerate(res):
+            assert np.array_equal(rec[r][0], o.lambdas()) and np.array_equal(rec[r][1], o.weights()), "round %d path %d" % (r, which)
+            assert np.float32(rec[r][2]) == np.float32(tmo)
+
+
 # ---- SURVEY.md 8f-4: feature sampling of Random Forests (FeatureHistogram.samplingRate), seeded ------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("ranker,frate,n_feat,leaves,seed", [
