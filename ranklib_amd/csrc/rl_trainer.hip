@@ -1299,7 +1299,10 @@ int rl_init(rl_trainer *t)
         }
         RL_HIP(t->pool.alloc(&t->d_wmax, (size_t)std::max(std::max(d.Q, (N + kThreads - 1) / kThreads), 2048) + 1));
         if (c.metric == RL_METRIC_MAP) RL_HIP(t->pool.alloc(&d.d_aux_i, (size_t)N));
-        if (c.metric == RL_METRIC_ERR) { RL_HIP(t->pool.alloc(&d.d_aux_a, (size_t)N)); RL_HIP(t->pool.alloc(&d.d_aux_b, (size_t)N)); }
+        if (c.metric == RL_METRIC_ERR) {     // R[] / np[]: the rank kernels only ever write the top min(k, n) positions of a list, the rest stays 0
+            RL_HIP(t->pool.alloc(&d.d_aux_a, (size_t)N)); RL_HIP(t->pool.alloc(&d.d_aux_b, (size_t)N));
+            RL_HIP(hipMemset(d.d_aux_a, 0, (size_t)N * sizeof(double))); RL_HIP(hipMemset(d.d_aux_b, 0, (size_t)N * sizeof(double)));
+        }
         RL_HIP(hipDeviceSynchronize());
         int rc = launch_rank(t, d, c.scores, d.d_ndcg, true);      // ranking of the all-zero start scores (file order)
         if (rc) return rc;
