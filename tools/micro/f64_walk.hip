@@ -3,7 +3,9 @@
 //           1 = the same, only lane 0 active (exec = 1)
 //           2 = lane l reads element 64 k + l once, elements reach the chain through v_readlane (SGPR operand)
 //           3 = as 2, the chain runs on lane 0 only
-//           4 = as 0 with ds_read_b128 (two elements per read)
+//           5 = FOUR chains per wavefront, one per row of 16 lanes: lane l reads element 16 k + (l & 15) of its row's list once, the
+//               row's lanes take element u through v_mov_b64_dpp row_newbcast:u (64-bit DPP knows only this pattern; v_add_f64 has no DPP form)
+//           6 = as 5, every element owned by ONE lane of the row (16 bins per row): s += (owner == lane) ? x : 0
 // hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/micro/f64_walk.hip -o tools/micro/bin/f64_walk
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -35,6 +37,22 @@ __global__ void k_walk(const double *x, int reps, double *out, long long *cyc)
                 AD(x0) AD(x1) AD(x2)
             }
         }
+    } else if (V == 5 || V == 6) {
+        const int row = lane >> 4, l16 = lane & 15;
+        const double *mine = lx + row * (T / 4);            // the row's list: T / 4 elements
+        for (int r = 0; r < reps; r++) {
+            double e = mine[l16], en;
+            for (int k = 0; k < T / 4; k += 16) {
+                en = mine[((k + 16) & (T / 4 - 1)) + l16];
+                const unsigned own = (unsigned)(__double2loint(e) >> 3) & 15u;       // V == 6: some owner lane
+#define STEP(u) { double b; asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:" #u " row_mask:0xf bank_mask:0xf" : "=v"(b) : "v"(e)); \
+                  if (V == 6) { unsigned ob; asm volatile("v_mov_b32_dpp %0, %1 row_newbcast:" #u " row_mask:0xf bank_mask:0xf" : "=v"(ob) : "v"(own)); \
+                                s += (ob == (unsigned)l16) ? b : 0.0; } else s += b; }
+                STEP(0) STEP(1) STEP(2) STEP(3) STEP(4) STEP(5) STEP(6) STEP(7) STEP(8) STEP(9) STEP(10) STEP(11) STEP(12) STEP(13) STEP(14) STEP(15)
+#undef STEP
+                e = en;
+            }
+        }
     } else {
         for (int r = 0; r < reps; r++) {
             double v = lx[lane], vn;
@@ -61,7 +79,8 @@ template <int V> void run(const double *x, double *out, long long *cyc)
     hipDeviceSynchronize();
     long long c; double r; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost); hipMemcpy(&r, out, 8, hipMemcpyDeviceToHost);
     const double n = (double)reps * (V <= 1 || V == 4 ? (T - 8) : T);
-    printf("variant %d: %.2f cycles per element (sum %.17g)\n", V, (double)c / n, r);
+    if (V >= 5) printf("variant %d: %.2f cycles per step of a row = %.2f cycles per element with four rows (sum %.17g)\n", V, (double)c / (n / 4), (double)c / n, r);
+    else printf("variant %d: %.2f cycles per element (sum %.17g)\n", V, (double)c / n, r);
 }
 int main()
 {
@@ -69,6 +88,6 @@ int main()
     hipMalloc(&x, T * 8); hipMalloc(&out, 64); hipMalloc(&cyc, 64);
     double h[T]; for (int i = 0; i < T; i++) h[i] = 1e-3 * (i % 17) - 7e-3 + 1e-9 * i;
     hipMemcpy(x, h, sizeof(h), hipMemcpyHostToDevice);
-    run<0>(x, out, cyc); run<1>(x, out, cyc); run<2>(x, out, cyc); run<3>(x, out, cyc);
+    run<0>(x, out, cyc); run<1>(x, out, cyc); run<2>(x, out, cyc); run<3>(x, out, cyc); run<5>(x, out, cyc); run<6>(x, out, cyc);
     return 0;
 }
