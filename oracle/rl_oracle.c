@@ -90,7 +90,8 @@ double ro_exp(double x)
 double ro_discount(int32_t i) { return 1.0 / (log((double)(i + 2)) / log(2.0)); }
 
 /* metric/DCGScorer.java:28-31: gain(l) = (1 << l) - 1 (int arithmetic) */
-static inline double gain_of(int rel) { return (double)((1 << rel) - 1); }
+static inline int32_t java_pow2m1(int32_t rel) { return (int32_t)(((uint32_t)1 << (rel & 31)) - 1u); }      /* Java: shift count mod 32, the subtraction wraps */
+static inline double gain_of(int rel) { return (double)java_pow2m1(rel); }
 
 /* ------------------------------------------------------------------------- */
 /* Stable index merge sort over natural runs -- utilities/MergeSorter.java:134-217.
@@ -430,7 +431,7 @@ static void ap_swap_change(const float *lab, int32_t n, double *changes)
 
 static double g_err_max = 16.0;                                                   /* ERRScorer.MAX (static, :25); -gmax sets 2^gmax */
 void ro_set_err_max(double m) { g_err_max = m; }
-static double err_R(int32_t rel) { return ((1 << rel) - 1) / g_err_max; }        /* ERRScorer.java:71-73 */
+static double err_R(int32_t rel) { return java_pow2m1(rel) / g_err_max; }        /* ERRScorer.java:71-73 */
 
 /* ERRScorer.swapChange (metric/ERRScorer.java:76-115): labels, R and np are only filled for the top `size`
  * positions (the rest stay 0), and np is the running product as written (p *= np[i]). */

@@ -135,7 +135,7 @@ static double ideal_dcg(const float *labels, int n, int topk, const std::vector<
     for (int i = 0; i < n; i++) rel[i] = (int)labels[i];
     std::sort(rel.begin(), rel.end(), [](int a, int b) { return a > b; });
     double dcg = 0;
-    for (int i = 0; i < topk; i++) dcg += (double)((1 << rel[i]) - 1) * disc[i];
+    for (int i = 0; i < topk; i++) dcg += (double)(int32_t)(((uint32_t)1 << (rel[i] & 31)) - 1u) * disc[i];      // Java int arithmetic (DCGScorer.java:137-139)
     return dcg;
 }
 
@@ -149,7 +149,9 @@ static int validate_dataset(const float *X, int64_t n, int32_t F, const float *l
         if (qoff[q + 1] <= qoff[q]) return fail(RL_ERR_INVALID, "qoff must be strictly increasing (empty ranked list)");
     for (int64_t i = 0; i < n; i++) {
         if (!(labels[i] >= 0)) return fail(RL_ERR_INVALID, "Relevance label cannot be negative. System will now exit.");  // DataPoint.java:71-73
-        if (labels[i] > 30.f) return fail(RL_ERR_UNSUPPORTED, "relevance label above 30 (gain 2^l-1 overflows int, DCGScorer.java:138)");
+        // labels above 30 are legal: the gain (1 << l) - 1 wraps as Java ints do (gain_of).  The Java keeps a gain cache of l + 10 doubles
+        // (DCGScorer.java:131-140), so a label near 2^31 ends in an OutOfMemoryError there; the line is drawn where (int)label is exact
+        if (labels[i] >= 16777216.f) return fail(RL_ERR_UNSUPPORTED, "relevance label of 2^24 or more");
     }
     return RL_OK;
 }

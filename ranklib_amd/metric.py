@@ -30,8 +30,13 @@ def discount(i):                      # metric/DCGScorer.java:26, utilities/Simp
     return 1.0 / (math.log(i + 2) / math.log(2))
 
 
-def gain(rel):                        # metric/DCGScorer.java:28-31
-    return float((1 << rel) - 1)
+def java_pow2m1(rel):                 # (1 << rel) - 1 in Java int arithmetic: shift count mod 32, wrapping subtraction
+    v = ((1 << (rel & 31)) - 1) & 0xFFFFFFFF
+    return v - (1 << 32) if v >= (1 << 31) else v
+
+
+def gain(rel):                        # metric/DCGScorer.java:28-31,137-139
+    return float(java_pow2m1(rel))
 
 
 class NDCGScorer(MetricScorer):       # metric/NDCGScorer.java:29-175
@@ -125,7 +130,7 @@ class ERRScorer(MetricScorer):        # metric/ERRScorer.java
         size = n if (self.k > n or self.k <= 0) else self.k
         s, p = 0.0, 1.0
         for i in range(1, size + 1):
-            R = ((1 << int(rl.get(i - 1).getLabel())) - 1) / self.MAX
+            R = java_pow2m1(int(rl.get(i - 1).getLabel())) / self.MAX
             s += p * R / i
             p *= (1.0 - R)
         return s

@@ -427,6 +427,48 @@ def test_fused_lambda_kernel_of_every_metric_on_mixed_list_lengths(metric, k, mo
             assert np.float32(rec[r][2]) == np.float32(tmo)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric", ["NDCG", "ERR", "DCG"])
+def test_labels_above_30_wrap_as_java_ints_do(metric):
+    """gain = (1 << label) - 1 is Java int arithmetic (metric/DCGScorer.java:28-31,137-139; ERRScorer.java:71-73): the shift count is taken
+    mod 32 and the subtraction wraps -- label 31 gives 2^31 - 1, 32 gives 0, 33 gives 1.  RankLib trains on such labels; so does this."""
+    rng = np.random.default_rng(5)
+    n = 4000
+    X = rng.random((n, 8)).astype(np.float32)
+    wild = np.array([0, 1, 2, 30, 31, 32, 33, 40, 63, 64, 1000], np.float32)
+    # ERR: R = gain / 16 above 1 squares |p| at every position until it overflows; the labels of the training run keep R below 1
+    lab = rng.choice(np.array([0, 1, 2, 3, 4, 32, 33, 34, 35, 36, 64, 68], np.float32) if metric == "ERR" else wild, n)
+    sizes = rng.integers(1, 40, 400)
+    qoff = np.concatenate([[0], np.cumsum(sizes)])
+    qoff = qoff[qoff < n].astype(np.int32)
+    qoff = np.concatenate([qoff, [n]]).astype(np.int32)
+    o = O.Oracle(X, lab, qoff, n_trees=4, n_leaves=8, metric=metric, k=10)
+    g = N.Trainer(n_trees=4, n_leaves=8, metric=metric, metric_k=10)
+    g.set_train(X, lab, qoff)
+    o.init(); g.init()
+    for r in range(4):
+        to, tmo, _, _ = o.round()
+        tg, tmg, _, _ = g.boost_round()
+        assert np.array_equal(g.array("LAMBDA").view(np.int64), o.lambdas().view(np.int64)), r
+        assert np.array_equal(g.array("WEIGHT").view(np.int64), o.weights().view(np.int64)), r
+        assert_equivalent(to, tg, X, ctx="round %d" % r)
+        assert np.array_equal(g.array("SCORE").view(np.int64), o.scores().view(np.int64)), r
+        assert np.float32(tmg).view(np.uint32) == np.float32(tmo).view(np.uint32)
+    assert o.finish()[0] == g.finish()[0]
+    if metric == "ERR":
+        # the overflow regime: np[] reaches +-Infinity inside the top ten and the swap changes turn Infinity / NaN exactly where the Java's do
+        # (its loop past the cutoff adds p * 0, NaN once p is infinite): the first round's lambdas, bit for bit including the NaNs
+        lab2 = rng.choice(wild, n)
+        o2 = O.Oracle(X, lab2, qoff, n_trees=1, n_leaves=4, metric="ERR", k=10)
+        g2 = N.Trainer(n_trees=1, n_leaves=4, metric="ERR", metric_k=10)
+        g2.set_train(X, lab2, qoff)
+        o2.init(); g2.init()
+        o2.round(); g2.boost_round()
+        assert not np.isfinite(o2.lambdas()).all()
+        assert np.array_equal(g2.array("LAMBDA").view(np.int64), o2.lambdas().view(np.int64))
+        assert np.array_equal(g2.array("WEIGHT").view(np.int64), o2.weights().view(np.int64))
+
+
 # ---- SURVEY.md 8f-4: feature sampling of Random Forests (FeatureHistogram.samplingRate), seeded ------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("ranker,frate,n_feat,leaves,seed", [

@@ -140,3 +140,22 @@ def test_err_max_static_changes_err_like_gmax():
     finally:
         O.set_err_max(16.0)
         M.ERRScorer.MAX = 16.0
+
+
+def test_gain_of_labels_above_30_is_java_int_arithmetic():
+    """(1 << i) - 1 with Java ints: shift count mod 32, wrapping subtraction (metric/DCGScorer.java:28-31,137-139) -- host mirror and oracle agree"""
+    from ranklib_amd import metric as M
+    assert [M.java_pow2m1(i) for i in (0, 1, 4, 30, 31, 32, 33, 63, 64, 1000)] == [0, 1, 15, 2 ** 30 - 1, 2 ** 31 - 1, 0, 1, 2 ** 31 - 1, 0, 255]
+    lab = np.array([31, 32, 33, 2, 0, 40], np.float32)
+    X = np.arange(12, dtype=np.float32).reshape(6, 2)
+    qoff = np.array([0, 6], np.int32)
+    o = O.Oracle(X, lab, qoff, n_trees=1, n_leaves=2, metric="DCG", k=10)
+    o.init()
+    _, tm, _, _ = o.round()
+    # the scorer of the host mirror on the same ranking gives the oracle's DCG
+    scores = o.scores()
+    order = sorted(range(6), key=lambda i: (-scores[i], i))
+    want = 0.0
+    for pos, i in enumerate(order):
+        want += M.gain(int(lab[i])) * M.discount(pos)
+    assert np.float32(want) == np.float32(tm)
