@@ -9,6 +9,7 @@ import math
 import sys
 
 from ._native import RankLibError
+from . import normalizer
 from .features import FeatureManager
 from .learning import (DataPoint, FeatureHistogram, LambdaMART, RankerFactory, RankerTrainer, RankerType, RFRanker, java_double_str, java_round,
                        stable_desc_order)
@@ -19,6 +20,8 @@ logger = logging.getLogger("ranklib_amd")
 
 class Evaluator:
     mustHaveRelDoc = False            # the reference's static of the same name (eval/Evaluator.java:551), set by -hr
+    normalize = False                 # eval/Evaluator.java:553-554, set by -norm
+    nml = normalizer.SumNormalizor()
 
     def __init__(self, rType, trainMetric, testMetric):
         self.type = rType
@@ -32,6 +35,12 @@ class Evaluator:
         validation = _read_input(validationFile) if validationFile else None
         test = _read_input(testFile) if testFile else None
         features = FeatureManager.readFeature(featureDefFile) if featureDefFile else FeatureManager.getFeatureFromSampleVector(train)
+        if Evaluator.normalize:                              # :687-695
+            self.normalizeLists(train, features)
+            if validation is not None:
+                self.normalizeLists(validation, features)
+            if test is not None:
+                self.normalizeLists(test, features)
         trainer = RankerTrainer()
         if validation is not None:
             ranker = trainer.train(self.type, train, validation, features, self.trainScorer)
@@ -49,6 +58,9 @@ class Evaluator:
     def _features(self, featureDefFile, samples):
         return FeatureManager.readFeature(featureDefFile) if featureDefFile else FeatureManager.getFeatureFromSampleVector(samples)
 
+    def normalizeLists(self, samples, fids=None):            # Evaluator.normalize(List<RankList>[, fids]) :629-639 (the static flag has the name here)
+        Evaluator.nml.normalizeAll(samples, fids)
+
     def _train(self, train, validation, features):
         trainer = RankerTrainer()
         if validation is not None:
@@ -58,8 +70,12 @@ class Evaluator:
     def evaluate_tts(self, sampleFile, validationFile, featureDefFile, percentTrain, modelFile=None):     # -tts  :716-739
         samples = _read_input(sampleFile)
         features = self._features(featureDefFile, samples)
+        if Evaluator.normalize:                              # prepareSplit :1329-1331: the whole file, before it is split
+            self.normalizeLists(samples, features)
         train, test = FeatureManager.prepareSplit(samples, percentTrain)
         validation = _read_input(validationFile) if validationFile else None
+        if validation is not None and Evaluator.normalize:   # :723-727
+            self.normalizeLists(validation, features)
         ranker = self._train(train, validation, features)
         s = self.testScorer.score(ranker.rank(test))
         logger.info("%s on test data: %s", self.testScorer.name(), java_round(s, 4))
@@ -71,8 +87,12 @@ class Evaluator:
     def evaluate_tvs(self, trainFile, percentTrain, testFile, featureDefFile, modelFile=None):            # -tvs  :749-773
         samples = _read_input(trainFile)
         features = self._features(featureDefFile, samples)
+        if Evaluator.normalize:
+            self.normalizeLists(samples, features)
         train, validation = FeatureManager.prepareSplit(samples, percentTrain)
         test = _read_input(testFile) if testFile else None
+        if test is not None and Evaluator.normalize:         # :756-760
+            self.normalizeLists(test, features)
         ranker = self._train(train, validation, features)
         s = None
         if test is not None:
@@ -87,6 +107,13 @@ class Evaluator:
         samples = _read_input(sampleFile)
         features = self._features(featureDefFile, samples)
         trainingData, validationData, testData = FeatureManager.prepareCV(samples, nFold, tvs)
+        if Evaluator.normalize:
+            # :816-822, kept as written: ALL folds are normalised once per fold, and the folds share their DataPoints (RankList's copy
+            # constructor), so a list is normalised nFold x (the number of folds it appears in) times -- not idempotent in float arithmetic
+            for _ in range(nFold):
+                for group in (trainingData, validationData, testData):
+                    for fold in group:
+                        self.normalizeLists(fold, features)
         scores, scoreOnTrain, scoreOnTest, totalScoreOnTest, totalTestSampleSize = [], 0.0, 0.0, 0.0, 0
         for i in range(nFold):
             ranker = self._train(trainingData[i], validationData[i] if tvs > 0 else None, features)
@@ -112,6 +139,8 @@ class Evaluator:
     def score(self, modelFile, testFile, outputFile):      # :1076-1094: qid \t index \t score
         ranker = self.rFact.loadRankerFromFile(modelFile)
         test = _read_input(testFile)
+        if Evaluator.normalize:                              # :1080-1082
+            self.normalizeLists(test, ranker.getFeatures())
         with open(outputFile, "w", encoding="utf-8") as out:
             for rl in test:
                 for j, v in enumerate(ranker.evalList(rl)):
@@ -120,6 +149,8 @@ class Evaluator:
     def rank(self, modelFile, testFile, indriFile):        # :1168-1194: qid Q0 docno rank score indri
         ranker = self.rFact.loadRankerFromFile(modelFile)
         test = _read_input(testFile)
+        if Evaluator.normalize:                              # :1173-1175
+            self.normalizeLists(test, ranker.getFeatures())
         with open(indriFile, "w", encoding="utf-8") as out:
             for rl in test:
                 sc = ranker.evalList(rl)
@@ -130,6 +161,8 @@ class Evaluator:
     def test(self, modelFile, testFile, prpFile=""):       # evaluate a saved model (:915-944); -idv: performance per ranked list
         ranker = self.rFact.loadRankerFromFile(modelFile)
         test = _read_input(testFile)
+        if Evaluator.normalize:                              # :919-921
+            self.normalizeLists(test, ranker.getFeatures())
         ids, scores, rankScore = [], [], 0.0
         for rl in test:
             l = ranker.rank(rl)
@@ -164,6 +197,7 @@ def main(argv=None):
         return 0
     trainFile = validationFile = testFile = featureDescriptionFile = savedModelFile = rankFile = indriRankingFile = scoreFile = modelFile = prpFile = ""
     Evaluator.mustHaveRelDoc = False
+    Evaluator.normalize = False                             # :86
     rankerType = 4                                          # the reference's default is Coordinate Ascent (:83)
     trainMetric, testMetric = "ERR@10", ""                  # the reference's default train metric (:84)
     ttSplit = tvSplit = 0.0
@@ -216,7 +250,10 @@ def main(argv=None):
         elif a == "-kcv": foldCV = int(nxt())
         elif a == "-kcvmd": kcvModelDir = nxt()
         elif a == "-kcvmn": kcvModelFile = nxt()
-        elif a in ("-round", "-epoch", "-tolerance", "-reg", "-r", "-i", "-norm",
+        elif a == "-norm":                                   # :256-267
+            Evaluator.nml = normalizer.create(nxt())
+            Evaluator.normalize = True
+        elif a in ("-round", "-epoch", "-tolerance", "-reg", "-r", "-i",
                    "-layer", "-node", "-lr", "-noeq", "-max", "-l2"):
             # parameters of the other rankers / of flows that are out of scope: parsed (the reference's own test passes
             # -round -epoch to every ranker, test:eval/EvaluatorTest.java:207-220) and ignored

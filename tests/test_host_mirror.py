@@ -434,3 +434,103 @@ def test_cli_idv_and_hr_flow(tmp_path):
     evaluator.main(["-load", model, "-test", p, "-metric2T", "NDCG@10", "-idv", out, "-hr"])
     rows = [l.split("   ") for l in open(out).read().splitlines()]
     assert [r[1] for r in rows] == ["b", "c", "all"] and abs(float(rows[2][2]) - (1.0 + c) / 2) < 1e-12
+
+
+# ---- -norm: features/SumNormalizor.java, ZScoreNormalizor.java, LinearNormalizer.java ----------------------------------------------
+def _literal_normalize(kind, rows, fids):
+    """the Java loops, one scalar operation at a time (numpy scalars for the float / double distinction)"""
+    f32, f64 = np.float32, np.float64
+    val = lambda r, f: (f32(0) if np.isnan(r[f]) else f32(r[f]))      # noqa: E731  getFeatureValue
+    n = len(rows)
+    if kind == "sum":
+        norm = [f64(0)] * len(fids)
+        for r in rows:
+            for j, f in enumerate(fids):
+                norm[j] = norm[j] + f64(abs(val(r, f)))
+        for r in rows:
+            for j, f in enumerate(fids):
+                if norm[j] > 0:
+                    r[f] = f32(f64(val(r, f)) / norm[j])
+    elif kind == "zscore":
+        means = [f64(0)] * len(fids)
+        for r in rows:
+            for j, f in enumerate(fids):
+                means[j] = means[j] + f64(val(r, f))
+        for j, f in enumerate(fids):
+            means[j] = means[j] / f64(n)
+            std = f64(0)
+            for r in rows:
+                x = f64(val(r, f)) - means[j]
+                std = std + x * x
+            with np.errstate(divide="ignore", invalid="ignore"):
+                std = np.sqrt(std / f64(n - 1))
+            if std > 0:
+                for r in rows:
+                    r[f] = f32((f64(val(r, f)) - means[j]) / std)
+    else:
+        for j, f in enumerate(fids):
+            lo, hi = np.finfo(f32).max, f32(1.4e-45)
+            for r in rows:
+                lo = min(lo, val(r, f)); hi = max(hi, val(r, f))
+            for r in rows:
+                r[f] = (val(r, f) - lo) / (hi - lo) if hi > lo else f32(0)
+
+
+@pytest.mark.parametrize("kind", ["sum", "zscore", "linear"])
+def test_normalizers_follow_the_java_loops_bit_for_bit(kind):
+    from ranklib_amd import normalizer as NM
+    from ranklib_amd.learning import DataPoint as DP, RankList as RL
+    rng = np.random.RandomState(3)
+    nm = NM.create(kind)
+    assert nm.name() == kind
+    for case in range(40):
+        n, F = int(rng.randint(1, 30)), 6
+        rows = (rng.randn(n, F + 1) * rng.choice([1e-3, 1.0, 1e4])).astype(np.float32)
+        rows[:, 2] = 7.5                                   # a constant column
+        rows[:, 3] = -np.abs(rows[:, 3])                   # no positive value: LinearNormalizer's max stays at Float.MIN_VALUE
+        rows[rng.rand(n) < 0.2, 4] = np.nan                # unknown values read as 0
+        fids = [1, 2, 3, 4, 6, 3] if case % 2 else None    # a feature list with a duplicate, or every feature
+        pts = [DP.from_parsed(1.0, "q", "", rows[i].copy()) for i in range(n)]
+        rl = RL(pts)
+        want = [rows[i].copy() for i in range(n)]
+        _literal_normalize(kind, want, sorted(set(fids)) if fids else list(range(1, F + 1)))
+        nm.normalize(rl, fids)
+        for i in range(n):
+            assert np.array_equal(pts[i].fVals[1:].view(np.uint32), want[i][1:].view(np.uint32)), (kind, case, i)
+
+
+def test_norm_flag_changes_the_training_data_and_unknown_normalizer_is_an_error(tmp_path):
+    from ranklib_amd import evaluator as E
+    with pytest.raises(Exception) as ei:
+        E.main(["-train", "x", "-norm", "bogus"])
+    assert "Unknown normalizor: bogus" in str(ei.value)
+    E.Evaluator.normalize = False
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["sum", "zscore", "linear"])
+def test_cli_norm_trains_on_the_normalised_lists(tmp_path, kind):
+    """-norm <method> (eval/Evaluator.java:256-267, :687-695): the model equals the one trained through the API on lists normalised by
+    hand, differs from the model of the raw data, and -rank / -load normalise the test lists with the model's features (:1173-1175)"""
+    from ranklib_amd import normalizer as NM
+    from ranklib_amd.features import FeatureManager
+    data, m_cli, m_raw, run = (str(tmp_path / n) for n in ("data.txt", "cli.txt", "raw.txt", "run.txt"))
+    write_random_data(data)
+    saved = (learning.LambdaMART.nTrees, learning.LambdaMART.nTreeLeaves)
+    try:
+        evaluator.main(["-train", data, "-ranker", "6", "-metric2t", "NDCG@10", "-tree", "6", "-leaf", "6", "-norm", kind, "-save", m_cli])
+        evaluator.main(["-rank", data, "-load", m_cli, "-norm", kind, "-indri", run])
+        evaluator.main(["-train", data, "-ranker", "6", "-metric2t", "NDCG@10", "-tree", "6", "-leaf", "6", "-save", m_raw])
+        assert evaluator.Evaluator.normalize is False          # the flag does not outlive a command line (:86)
+        lists = FeatureManager.readInput(data)
+        feats = FeatureManager.getFeatureFromSampleVector(lists)
+        NM.create(kind).normalizeAll(lists, feats)
+        learning.LambdaMART.nTrees, learning.LambdaMART.nTreeLeaves = 6, 6
+        from ranklib_amd.metric import MetricScorerFactory
+        r = learning.RankerTrainer().train(learning.RankerType.LAMBDAMART, lists, feats, MetricScorerFactory().createScorer("NDCG@10"))
+    finally:
+        learning.LambdaMART.nTrees, learning.LambdaMART.nTreeLeaves = saved
+    cli = open(m_cli).read()
+    assert cli[cli.index("<ensemble>"):] == r.model()[r.model().index("<ensemble>"):]
+    assert cli[cli.index("<ensemble>"):] != open(m_raw).read()[open(m_raw).read().index("<ensemble>"):]
+    assert len(open(run).read().splitlines()) > 0
