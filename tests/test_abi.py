@@ -80,3 +80,39 @@ def test_c_example_trains_through_the_abi(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "## LambdaMART" in out.stdout and "<ensemble>" in out.stdout and out.stdout.count("<tree id=") == 10
+
+
+# ---- the JNI shim (integration/jni/RlHipNative.c): no JDK in this image, so no build -- but it can be TYPE-checked --------------------
+def test_jni_shim_type_checks_against_the_jni_signatures(tmp_path):
+    """gcc -fsyntax-only against tests/stubs/jni.h, a minimal stand-in that declares the JNINativeInterface_ entries the shim calls with the
+    signatures of the JNI specification, and against include/rlhip.h: wrong argument counts / types on either side fail here"""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Werror", "-fsyntax-only",
+                        "-I", os.path.join(ROOT, "tests", "stubs"), "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "integration", "jni", "RlHipNative.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_java_native_declarations_match_the_shim():
+    """every `static native` of RlHipNative.java has its Java_<class>_<method> in the shim with JNIEnv*, jclass and the mapped parameter
+    types in order (a mismatch is an UnsatisfiedLinkError or a corrupted call at run time, not a compile error, on the Java side)"""
+    import re
+    java = open(os.path.join(ROOT, "integration", "java", "ciir", "umass", "edu", "learning", "tree", "RlHipNative.java")).read()
+    csrc = open(os.path.join(ROOT, "integration", "jni", "RlHipNative.c")).read()
+    tmap = {"long": "jlong", "int": "jint", "float": "jfloat", "boolean": "jboolean", "double": "jdouble", "FloatBuffer": "jobject",
+            "float[]": "jfloatArray", "int[]": "jintArray", "double[]": "jdoubleArray", "void": "void"}
+    decls = re.findall(r"static\s+native\s+([\w\[\]]+)\s+(\w+)\s*\(([^)]*)\)\s*;", java, re.S)
+    assert len(decls) >= 8
+    for ret, name, args in decls:
+        want = ["JNIEnv *", "jclass"] + [tmap[" ".join(a.split()[:-1])] for a in args.split(",") if a.strip()]
+        m = re.search(r"JNIEXPORT\s+(\w+)\s+JNICALL\s+Java_ciir_umass_edu_learning_tree_RlHipNative_%s\s*\(([^)]*)\)" % name, csrc, re.S)
+        assert m, "no JNI entry point for " + name
+        assert m.group(1) == tmap[ret], (name, m.group(1), ret)
+        got = []
+        for a in m.group(2).split(","):
+            a = " ".join(a.split())
+            got.append("JNIEnv *" if a.startswith("JNIEnv") else a.rsplit(" ", 1)[0])
+        assert got == want, (name, got, want)
