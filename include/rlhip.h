@@ -147,6 +147,15 @@ int rl_set_validation(rl_trainer *t, const float *X, int64_t n_docs, const float
  * in consecutive blocks, first_doc ascending from 0, before rl_init.  X: row-major [n_docs][n_features] of that block. */
 int rl_set_rows(rl_trainer *t, int32_t validation, int64_t first_doc, int64_t n_docs, const float *X);
 
+/* -qrel <file> (eval/Evaluator.java:243-244, :580-591): external relevance judgments, resolved per ranked list by the caller.
+ *   ideal_dcg[Q]      NDCG: the entry NDCGScorer.loadExternalRelevanceJudgment (metric/NDCGScorer.java:50-96) put into idealGains for the
+ *                     list's qid -- it is in the cache before any list is scored, so the list never computes its own; NaN = the qid is not
+ *                     in the file.  NULL = no external ideal gains.
+ *   rel_doc_count[Q]  MAP: relDocCount of the list's qid (metric/APScorer.java:45-66), 0 when the qid is not in the file (the Java then scores
+ *                     the list 0 and returns all-zero swap changes, :86-94, :124-143).  NULL = every list counts its own relevant documents.
+ * After rl_set_train / rl_set_validation of that data set, before rl_init.  Single GPU. */
+int rl_set_external_judgments(rl_trainer *t, int32_t validation, const double *ideal_dcg, const int32_t *rel_doc_count);
+
 int rl_init(rl_trainer *t);
 
 /* One boosting round, synchronous.  out may be NULL.  *stop is set to 1 when the early-stop test

@@ -279,6 +279,9 @@ typedef struct {            /* one data set (train or validation) */
     float   *labels;
     int32_t *qoff;
     int32_t *qkey;          /* may be NULL */
+    /* -qrel (eval/Evaluator.java:580-591): external relevance judgments resolved per query by the caller */
+    double  *ext_ideal;     /* NDCGScorer.loadExternalRelevanceJudgment: idealGains entry of the list's qid, NaN = none (may be NULL) */
+    int32_t *ext_rd;        /* APScorer.loadExternalRelevanceJudgment: relDocCount of the list's qid, 0 when the qid is not in the file (NULL = no -qrel) */
 } dataset_t;
 
 typedef struct {            /* kept model: learning/tree/Ensemble.java:33-35 */
@@ -402,8 +405,12 @@ static double ndcg_score_ranked(ro_trainer *t, const int32_t *rel, int32_t n, in
     return dcg / ideal;
 }
 
+/* rdCount of the list being processed when an external judgment file is loaded (APScorer.java:124-133, :86-94); -1 = relDocCount == null.
+ * Set by the per-query callers (they run inside pool threads). */
+static __thread int32_t g_ext_rd = -1;
+
 /* APScorer.swapChange (metric/APScorer.java:108-162) on float labels in ranked order; changes = n*n row-major.
- * K is ignored ("consider the entire ranked list"); no external relevance judgments (relDocCount == null). */
+ * K is ignored ("consider the entire ranked list"). */
 static void ap_swap_change(const float *lab, int32_t n, double *changes)
 {
     int32_t *relCount = (int32_t *)malloc(sizeof(int32_t) * (size_t)(2 * n + 2)), *labels = relCount + n + 1;
@@ -412,7 +419,7 @@ static void ap_swap_change(const float *lab, int32_t n, double *changes)
         if (lab[i] > 0) { labels[i] = 1; count++; } else labels[i] = 0;       /* :113-121 (float compare) */
         relCount[i] = count;
     }
-    const int32_t rdCount = count;                                            /* :131-133 */
+    const int32_t rdCount = g_ext_rd >= 0 ? g_ext_rd : count;                  /* :124-133 */
     memset(changes, 0, sizeof(double) * (size_t)n * (size_t)n);
     if (rdCount == 0 || count == 0) { free(relCount); return; }               /* :141-143 */
     for (int32_t i = 0; i < n - 1; i++)
@@ -480,8 +487,9 @@ static double ap_score_ranked(const float *lab, int32_t n)
 {
     double ap = 0.0; int32_t count = 0;
     for (int32_t i = 0; i < n; i++) if (lab[i] > 0.0) { count++; ap += ((double)count) / (i + 1); }
-    if (count == 0) return 0.0;
-    return ap / count;
+    const int32_t rdCount = g_ext_rd >= 0 ? g_ext_rd : count;                  /* APScorer.java:86-94 */
+    if (rdCount == 0) return 0.0;
+    return ap / rdCount;
 }
 static double err_score_ranked(const float *lab, int32_t n, int32_t k)
 {
@@ -581,6 +589,7 @@ void ro_query_lambdas_metric(int32_t metric, const double *scores, const float *
     int32_t *buf = (int32_t *)malloc(sizeof(int32_t) * (size_t)(4 * n + 4));
     memset(lambda, 0, sizeof(double) * (size_t)n);
     memset(weight, 0, sizeof(double) * (size_t)n);
+    g_ext_rd = -1;
     query_lambdas(NULL, scores, labels, 0, n, k, -1, metric == RO_METRIC_NDCG ? -1.0 : -2.0 - metric, lambda, weight,
                   buf, buf + n, buf + 3 * n + 2);
     free(buf);
@@ -592,6 +601,7 @@ double ro_query_score(int32_t metric, const double *scores, const float *labels,
     int32_t *buf = (int32_t *)malloc(sizeof(int32_t) * (size_t)(4 * n + 4));
     int32_t *idx = buf, *tmp = buf + n, *rel = buf + 3 * n + 2;
     sort_idx(scores, 0, n, 0, idx, tmp, tmp + n);
+    g_ext_rd = -1;
     const double r = query_score(NULL, metric, labels, idx, n, k, -1, rel, tmp);
     free(buf);
     return r;
@@ -638,6 +648,7 @@ float ro_float_chain(const double *x, const int32_t *idx, int32_t n)
 /* ------------------------------------------------------------------------- */
 /* create / destroy                                                            */
 /* ------------------------------------------------------------------------- */
+static int32_t query_key(const dataset_t *d, int32_t q, int32_t base);
 static void dataset_set(dataset_t *d, const float *X, int64_t n, int32_t F, const float *labels,
                         const int32_t *qoff, int32_t q, const int32_t *qkey, int copyX)
 {
@@ -646,7 +657,7 @@ static void dataset_set(dataset_t *d, const float *X, int64_t n, int32_t F, cons
     memcpy(d->labels, labels, sizeof(float) * (size_t)n);
     d->qoff = (int32_t *)malloc(sizeof(int32_t) * (size_t)(q + 1));
     memcpy(d->qoff, qoff, sizeof(int32_t) * (size_t)(q + 1));
-    d->qkey = NULL;
+    d->qkey = NULL; d->ext_ideal = NULL; d->ext_rd = NULL;
     if (qkey) {
         d->qkey = (int32_t *)malloc(sizeof(int32_t) * (size_t)(q ? q : 1));
         memcpy(d->qkey, qkey, sizeof(int32_t) * (size_t)q);
@@ -687,6 +698,14 @@ void ro_set_validation(ro_trainer *t, const float *X, int64_t n_docs, const floa
     t->has_valid = 1;
 }
 
+void ro_set_external(ro_trainer *t, int validation, const double *ideal, const int32_t *rel_count)
+{
+    dataset_t *d = validation ? &t->va : &t->tr;
+    free(d->ext_ideal); free(d->ext_rd); d->ext_ideal = NULL; d->ext_rd = NULL;
+    if (ideal) { d->ext_ideal = (double *)malloc(sizeof(double) * (size_t)(d->q + 1)); memcpy(d->ext_ideal, ideal, sizeof(double) * (size_t)d->q); }
+    if (rel_count) { d->ext_rd = (int32_t *)malloc(sizeof(int32_t) * (size_t)(d->q + 1)); memcpy(d->ext_rd, rel_count, sizeof(int32_t) * (size_t)d->q); }
+}
+
 static void free_kept(kept_tree *k)
 {
     free(k->feature); free(k->threshold); free(k->left); free(k->right); free(k->output);
@@ -704,8 +723,8 @@ void ro_destroy(ro_trainer *t)
     free(t->root.sum); free(t->root.count);
     free(t->modelScores); free(t->pseudoResponses); free(t->weights); free(t->validScores);
     free(t->Xcol);
-    free(t->tr.labels); free(t->tr.qoff); free(t->tr.qkey);
-    free(t->va.labels); free(t->va.qoff); free(t->va.qkey); free(t->va.Xown);
+    free(t->tr.labels); free(t->tr.qoff); free(t->tr.qkey); free(t->tr.ext_ideal); free(t->tr.ext_rd);
+    free(t->va.labels); free(t->va.qoff); free(t->va.qkey); free(t->va.Xown); free(t->va.ext_ideal); free(t->va.ext_rd);
     free(t->ck); free(t->cv); free(t->cu);
     for (int32_t i = 0; i < t->n_trees; i++) free_kept(&t->trees[i]);
     free(t->trees);
@@ -790,6 +809,10 @@ void ro_init(ro_trainer *t)
     disc_reserve(maxq + 2);
     cache_init(t, t->tr.q + t->va.q);
     t->next_anon_key = 0;
+    /* -qrel: NDCGScorer.loadExternalRelevanceJudgment puts the file's ideal DCGs into idealGains BEFORE any list is scored (:50-96), so
+     * lists with such a qid never compute their own (the scorer object is shared by training and validation, Evaluator.java:580-591) */
+    for (int32_t q = 0; q < t->tr.q; q++) if (t->tr.ext_ideal && t->tr.ext_ideal[q] == t->tr.ext_ideal[q]) cache_put(t, query_key(&t->tr, q, 0), t->tr.ext_ideal[q]);
+    for (int32_t q = 0; q < t->va.q; q++) if (t->va.ext_ideal && t->va.ext_ideal[q] == t->va.ext_ideal[q]) cache_put(t, query_key(&t->va, q, t->tr.q), t->va.ext_ideal[q]);
 
     /* sort samples by each feature (:94-105) */
     init_ctx c; c.t = t;
@@ -862,6 +885,7 @@ static void lambda_chunk(void *c_, int32_t qs, int32_t qe, int32_t worker)
     int32_t *buf = (int32_t *)malloc(sizeof(int32_t) * (size_t)(4 * t->maxq + 4));
     for (int32_t q = qs; q <= qe; q++) {
         const int32_t cur = t->tr.qoff[q], n = t->tr.qoff[q + 1] - cur;
+        g_ext_rd = t->tr.ext_rd ? t->tr.ext_rd[q] : -1;
         query_lambdas(t, t->modelScores, t->tr.labels, cur, n, t->p.metric_k, query_key(&t->tr, q, 0), -1.0,
                       t->pseudoResponses, t->weights, buf, buf + n, buf + 3 * n + 2);
     }
@@ -1212,6 +1236,7 @@ static float model_score(ro_trainer *t, const dataset_t *d, const double *scores
         const int32_t cur = d->qoff[q], n = d->qoff[q + 1] - cur;
         int32_t *idx = buf, *tmp = buf + n, *rel = buf + 3 * n + 2;
         sort_idx(scores, cur, n, 0, idx, tmp, tmp + n);           /* rank(), :432-440 */
+        g_ext_rd = d->ext_rd ? d->ext_rd[q] : -1;
         const double sc = query_score(t, t->p.metric, d->labels, idx, n, t->p.metric_k, query_key(d, q, keybase), rel, tmp);
         s = (float)((double)s + sc);                              /* float s; s += double  :479 */
     }
@@ -1379,6 +1404,7 @@ static double final_score(ro_trainer *t, const dataset_t *d, const float *X, int
         const int32_t cur = d->qoff[q], n = d->qoff[q + 1] - cur;
         int32_t *idx = buf, *tmp = buf + n, *rel = buf + 3 * n + 2;
         sort_idx(sc, cur, n, 0, idx, tmp, tmp + n);
+        g_ext_rd = d->ext_rd ? d->ext_rd[q] : -1;
         score += query_score(t, t->p.metric, d->labels, idx, n, t->p.metric_k, query_key(d, q, keybase), rel, tmp);
     }
     free(buf); free(sc); free(ev);

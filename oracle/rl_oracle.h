@@ -80,6 +80,9 @@ ro_trainer *ro_create(const ro_params *p,
 void ro_set_validation(ro_trainer *t, const float *X, int64_t n_docs,
                        const float *labels, const int32_t *qoff, int32_t n_queries,
                        const int32_t *qkey);
+/* -qrel (eval/Evaluator.java:580-591): per query, the idealGains entry its qid has in the judgment file (NaN = none; NDCG) and its
+ * relDocCount (0 when the qid is absent; MAP).  NULL = that scorer has no external judgments.  Before ro_init, after the data set. */
+void ro_set_external(ro_trainer *t, int validation, const double *ideal, const int32_t *rel_count);
 void ro_destroy(ro_trainer *t);
 
 /* LambdaMART.init()  learning/tree/LambdaMART.java:68-166 */

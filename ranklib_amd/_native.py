@@ -44,7 +44,7 @@ KERNEL = dict(HIST_ROOT=0, HIST_NODE=1, LAMBDA=2)
 # every symbol include/rlhip.h declares (tests/test_abi.py checks the .so exports all of them)
 ABI_SYMBOLS = [
     "rl_abi_version", "rl_last_error", "rl_device_count", "rl_params_default", "rl_create", "rl_destroy",
-    "rl_set_train", "rl_set_validation", "rl_set_rows", "rl_init", "rl_boost_round", "rl_boost_rounds_async", "rl_sync",
+    "rl_set_train", "rl_set_validation", "rl_set_rows", "rl_set_external_judgments", "rl_init", "rl_boost_round", "rl_boost_rounds_async", "rl_sync",
     "rl_finish", "rl_num_trees", "rl_get_tree", "rl_get_round_metrics", "rl_best_validation", "rl_predict",
     "rl_model_to_text", "rl_model_from_text", "rl_model_destroy", "rl_model_num_trees", "rl_model_features",
     "rl_model_predict", "rl_model_predict_device", "rl_dist_unique_id", "rl_dist_init", "rl_dist_init_callback", "rl_dist_stats", "rl_bin_stride", "rl_quant_exponent", "rl_get_array", "rl_debug_exp", "rl_debug_float_chain",
@@ -80,6 +80,7 @@ def lib():
     L.rl_set_train.argtypes = [vp, vp, i64, i32, vp, vp, i32, vp, vp]
     L.rl_set_validation.argtypes = [vp, vp, i64, vp, vp, i32, vp]
     L.rl_set_rows.argtypes = [vp, i32, i64, i64, vp]
+    L.rl_set_external_judgments.argtypes = [vp, i32, vp, vp]
     L.rl_init.argtypes = [vp]
     L.rl_boost_round.argtypes = [vp, C.POINTER(RlTree), f32p, f32p, C.POINTER(i32)]
     L.rl_boost_rounds_async.argtypes = [vp, i32]
@@ -262,6 +263,13 @@ class Trainer:
         for a in range(0, X.shape[0], chunk_rows):
             blk = np.ascontiguousarray(X[a:a + chunk_rows])
             check(lib().rl_set_rows(self.h, 1 if validation else 0, a, blk.shape[0], blk.ctypes.data))
+
+    def set_external_judgments(self, validation, ideal_dcg=None, rel_doc_count=None):
+        """-qrel: per list, its qid's idealGains entry from the judgment file (NaN = none) / its relDocCount (0 = qid not in the file)"""
+        idl = None if ideal_dcg is None else np.ascontiguousarray(ideal_dcg, dtype=np.float64)
+        rdc = None if rel_doc_count is None else np.ascontiguousarray(rel_doc_count, dtype=np.int32)
+        check(lib().rl_set_external_judgments(self.h, 1 if validation else 0, None if idl is None else idl.ctypes.data,
+                                              None if rdc is None else rdc.ctypes.data))
 
     def set_validation(self, X, labels, qoff, qkey=None):
         X, labels, qoff, qk = self._prep(X, labels, qoff, qkey)

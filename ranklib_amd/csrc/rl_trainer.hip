@@ -57,6 +57,8 @@ struct DataSet {
     double *d_scores = nullptr, *d_ndcg = nullptr;
     double *d_ss = nullptr; float *d_sl = nullptr; int32_t *d_srel = nullptr, *d_sidx = nullptr, *d_docq = nullptr;   // ranked order (training set only)
     int32_t *d_aux_i = nullptr; double *d_aux_a = nullptr, *d_aux_b = nullptr;   // swapChange tables of MAP / ERR in ranked order
+    // -qrel (rl_set_external_judgments): per list, the idealGains entry of its qid in the judgment file (NaN = none) and its relDocCount
+    std::vector<double> ext_ideal; std::vector<int32_t> ext_rd; int32_t *d_ext_rd = nullptr;
     int32_t *d_qsmall = nullptr, *d_qbig = nullptr, *d_qtiny = nullptr; int32_t n_small = 0, n_big = 0, n_tiny = 0; bool all_small = false;
     int32_t *d_qhuge = nullptr, *d_relscratch = nullptr; int32_t n_huge = 0;      // lists beyond kLambdaBlockCap documents (k_rank_huge)
     // queries by length class for the fused lambda kernel: <= 64, <= 128, <= 192 documents, longer (tiled by 256); a block is as
@@ -378,7 +380,8 @@ static int launch_rank(rl_trainer *t, DataSet &d, const double *scores, double *
 {
     RankArgs a{scores, d.d_labels, d.d_qoff, d.d_ideal1, t->ctx.disc,
                ranked ? d.d_ss : nullptr, ranked ? d.d_sl : nullptr, ranked ? d.d_srel : nullptr, ranked ? d.d_sidx : nullptr,
-               out, t->p.metric_k, t->p.metric, ranked ? d.d_aux_i : nullptr, ranked ? d.d_aux_a : nullptr, ranked ? d.d_aux_b : nullptr, t->err_max};
+               out, t->p.metric_k, t->p.metric, ranked ? d.d_aux_i : nullptr, ranked ? d.d_aux_a : nullptr, ranked ? d.d_aux_b : nullptr, t->err_max,
+               d.d_ext_rd};
     if (d.n_tiny > 0)
         hipLaunchKernelGGL(k_rank_tiny, dim3((d.n_tiny + kRankTinyGroups - 1) / kRankTinyGroups), dim3(kRankTinyDocs * kRankTinyGroups), 0, t->stream, a,
                            (const int *)d.d_qtiny, d.n_tiny);
@@ -439,7 +442,7 @@ static int enqueue_round(rl_trainer *t)
         const double *ideal = (c.metric == RL_METRIC_NDCG) ? (m == 0 ? c.ideal0 : c.ideal1) : nullptr;
         LamArgs g{t->tr.d_ss, t->tr.d_sl, t->tr.d_srel, t->tr.d_sidx, c.qoff, t->tr.d_docq, ideal, c.disc,
                   t->d_T, c.lw, &c.st->maxabs_bits, c.N, c.k, c.k, c.metric, t->p.metric_k,
-                  t->tr.d_aux_i, t->tr.d_aux_a, t->tr.d_aux_b, t->d_wmax};
+                  t->tr.d_aux_i, t->tr.d_aux_a, t->tr.d_aux_b, t->d_wmax, t->tr.d_ext_rd};
         if (t->d_T == nullptr) {
             const int mode = (c.metric == RL_METRIC_ERR) ? 1 : (c.metric == RL_METRIC_MAP) ? 2 : 0;
             auto lds_of = [&](int bt) { return (size_t)c.k * (bt + 8) * 16 + (size_t)c.k * 24 + lambda_fused_extra_bytes(mode, c.k, bt); };
@@ -746,6 +749,22 @@ void rl_params_default(rl_params *p)
     p->learning_rate = 0.1F; p->metric = RL_METRIC_NDCG; p->metric_k = 10; p->device = 0; p->flags = 0;
     p->ranker = RL_RANKER_LAMBDAMART;
     p->feature_sampling_rate = 1.0f; p->seed = 0;
+}
+
+int rl_set_external_judgments(rl_trainer *t, int32_t validation, const double *ideal_dcg, const int32_t *rel_doc_count)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    if (t->inited) return fail(RL_ERR_STATE, "rl_set_external_judgments must be called before rl_init");
+    if (validation ? !t->has_valid : !t->has_train) return fail(RL_ERR_STATE, "set the data first");
+    if (t->dist) return fail(RL_ERR_UNSUPPORTED, "external relevance judgments with multi-GPU training");
+    DataSet &d = validation ? t->va : t->tr;
+    d.ext_ideal.clear(); d.ext_rd.clear();
+    if (ideal_dcg) d.ext_ideal.assign(ideal_dcg, ideal_dcg + d.Q);
+    if (rel_doc_count) {
+        for (int q = 0; q < d.Q; q++) if (rel_doc_count[q] < 0) return fail(RL_ERR_INVALID, "negative relevant-document count");
+        d.ext_rd.assign(rel_doc_count, rel_doc_count + d.Q);
+    }
+    return RL_OK;
 }
 
 int rl_set_err_max(double max_gain)
@@ -1145,18 +1164,34 @@ int rl_init(rl_trainer *t)
     c.disc = d_disc;
     {
         std::map<int64_t, double> cache;
+        // -qrel: NDCGScorer.loadExternalRelevanceJudgment fills idealGains BEFORE any list is scored (:50-96): those qids never compute their own
+        auto preload = [&](DataSet &d, int64_t anon_base) {
+            for (int q = 0; q < d.Q && !d.ext_ideal.empty(); q++)
+                if (d.ext_ideal[q] == d.ext_ideal[q]) cache[d.has_key ? (int64_t)d.qkey[q] : anon_base + q] = d.ext_ideal[q];
+        };
+        preload(t->tr, (int64_t)1 << 40);
+        if (t->has_valid) preload(t->va, (int64_t)1 << 41);
+        const std::map<int64_t, double> external = cache;
         auto run = [&](DataSet &d, int64_t anon_base, std::vector<double> &own, std::vector<double> &cached) {
             own.resize(d.Q); cached.resize(d.Q);
             for (int q = 0; q < d.Q; q++) {
                 const int n = d.qoff[q + 1] - d.qoff[q];
                 const int size = std::min(n, t->p.metric_k);
-                own[q] = ideal_dcg(d.labels.data() + d.qoff[q], n, size, disc);
                 const int64_t key = d.has_key ? (int64_t)d.qkey[q] : anon_base + q;
+                { auto pre = external.find(key); if (pre != external.end()) { own[q] = cached[q] = pre->second; continue; } }
+                own[q] = ideal_dcg(d.labels.data() + d.qoff[q], n, size, disc);
                 auto it = cache.find(key);
                 if (it == cache.end()) it = cache.emplace(key, own[q]).first;   // score() fills the cache in list order
                 cached[q] = it->second;
             }
         };
+        auto upload_rd = [&](DataSet &d) -> int {
+            if (d.ext_rd.empty()) return RL_OK;
+            RL_HIP(t->pool.alloc(&d.d_ext_rd, (size_t)d.Q));
+            RL_HIP(hipMemcpy(d.d_ext_rd, d.ext_rd.data(), (size_t)d.Q * sizeof(int32_t), hipMemcpyHostToDevice));
+            return RL_OK;
+        };
+        { int rcu = upload_rd(t->tr); if (rcu) return rcu; if (t->has_valid) { rcu = upload_rd(t->va); if (rcu) return rcu; } }
         std::vector<double> own, cached;
         run(t->tr, (int64_t)1 << 40, own, cached);
         int rc = upload_query_side(t, t->tr, own, cached);

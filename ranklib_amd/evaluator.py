@@ -22,12 +22,16 @@ class Evaluator:
     mustHaveRelDoc = False            # the reference's static of the same name (eval/Evaluator.java:551), set by -hr
     normalize = False                 # eval/Evaluator.java:553-554, set by -norm
     nml = normalizer.SumNormalizor()
+    qrelFile = ""                     # :557, set by -qrel: TREC-style judgments, they only affect MAP and NDCG
 
     def __init__(self, rType, trainMetric, testMetric):
         self.type = rType
         mf = MetricScorerFactory()
         self.trainScorer = mf.createScorer(trainMetric)
         self.testScorer = mf.createScorer(testMetric)
+        if Evaluator.qrelFile:                              # :579-582
+            self.trainScorer.loadExternalRelevanceJudgment(Evaluator.qrelFile)
+            self.testScorer.loadExternalRelevanceJudgment(Evaluator.qrelFile)
         self.rFact = RankerFactory()
 
     def evaluate(self, trainFile, validationFile=None, testFile=None, featureDefFile=None, modelFile=None):   # :669-708
@@ -198,6 +202,7 @@ def main(argv=None):
     trainFile = validationFile = testFile = featureDescriptionFile = savedModelFile = rankFile = indriRankingFile = scoreFile = modelFile = prpFile = ""
     Evaluator.mustHaveRelDoc = False
     Evaluator.normalize = False                             # :86
+    Evaluator.qrelFile = ""
     rankerType = 4                                          # the reference's default is Coordinate Ascent (:83)
     trainMetric, testMetric = "ERR@10", ""                  # the reference's default train metric (:84)
     ttSplit = tvSplit = 0.0
@@ -250,6 +255,7 @@ def main(argv=None):
         elif a == "-kcv": foldCV = int(nxt())
         elif a == "-kcvmd": kcvModelDir = nxt()
         elif a == "-kcvmn": kcvModelFile = nxt()
+        elif a == "-qrel": Evaluator.qrelFile = nxt()       # :243-244
         elif a == "-norm":                                   # :256-267
             Evaluator.nml = normalizer.create(nxt())
             Evaluator.normalize = True

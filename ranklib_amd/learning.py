@@ -305,6 +305,20 @@ class LambdaMART(Ranker):
                 ids.setdefault(rl.getID(), int(qkey[q]))
             vkey = np.array([ids.setdefault(rl.getID(), nk + i) for i, rl in enumerate(self.validationSamples)], np.int32)
             t.set_validation(Xv, lv, qv, qkey=vkey)
+        # what the scorer object already holds reaches the trainer list by list: idealGains entries (-qrel, NDCGScorer.java:50-96 -- or any
+        # earlier use of the same scorer object: a cached entry is a cached entry) and relDocCount (-qrel, APScorer.java:45-66)
+        for validation, lists in ((False, self.samples), (True, self.validationSamples)):
+            if lists is None:
+                continue
+            ideal = rdc = None
+            gains = getattr(self.scorer, "idealGains", None)
+            if metric == "NDCG" and gains:
+                ideal = np.array([gains.get(rl.getID(), np.nan) for rl in lists], np.float64)
+            counts = getattr(self.scorer, "relDocCount", None)
+            if metric == "MAP" and counts is not None:
+                rdc = np.array([counts.get(rl.getID(), 0) for rl in lists], np.int32)
+            if ideal is not None or rdc is not None:
+                t.set_external_judgments(validation, ideal, rdc)
         t.init()
         self._trainer = t
 

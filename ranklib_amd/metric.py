@@ -4,6 +4,8 @@ metric/MetricScorerFactory.java.  The per-round training / validation metric (ND
 GPU; these classes only score already-ranked lists for the test-time report, as Evaluator does."""
 import math
 
+import numpy as np
+
 from ._native import RankLibError
 
 
@@ -16,6 +18,9 @@ class MetricScorer:                   # metric/MetricScorer.java:20-69
 
     def getK(self):
         return self.k
+
+    def loadExternalRelevanceJudgment(self, qrelFile):     # :42-44: only MAP and NDCG do something with it
+        pass
 
     def score(self, rl):
         if isinstance(rl, list):      # score(List<RankList>): double mean  :46-52
@@ -39,10 +44,43 @@ def gain(rel):                        # metric/DCGScorer.java:28-31,137-139
     return float(java_pow2m1(rel))
 
 
+def _qrel_lines(qrelFile):            # the loops of loadExternalRelevanceJudgment: trimmed lines split on ONE space, qid = s[0], label = rint(s[3])
+    import gzip
+    with (gzip.open(qrelFile, "rt", encoding="utf-8") if qrelFile.endswith(".gz") else open(qrelFile, "r", encoding="utf-8")) as f:   # FileUtils.smartReader
+        for content in f:
+            content = content.strip()
+            if not content:
+                continue
+            s = content.split(" ")
+            yield s[0].strip(), int(round_half_even(float(s[3].strip())))
+
+
+def round_half_even(x):               # Math.rint
+    return float(np.rint(x))
+
+
 class NDCGScorer(MetricScorer):       # metric/NDCGScorer.java:29-175
     def __init__(self, k=10):
         super().__init__(k)
         self.idealGains = {}
+
+    def getIdealDCG(self, rel, topK):  # DCGScorer.getIdealDCG via NDCGScorer.java:162-174: the topK largest labels, best first
+        r = sorted(rel, reverse=True)
+        dcg = 0.0
+        for i in range(topK):
+            dcg += gain(r[i]) * discount(i)
+        return dcg
+
+    def loadExternalRelevanceJudgment(self, qrelFile):     # :50-96: one idealGains entry per RUN of lines with the same qid (a later run overwrites)
+        lastQID, rel = "", []
+        for qid, label in _qrel_lines(qrelFile):
+            if lastQID and lastQID != qid:
+                self.idealGains[lastQID] = self.getIdealDCG(rel, self.k if len(rel) > self.k else len(rel))
+                rel = []
+            lastQID = qid
+            rel.append(label)
+        if rel:
+            self.idealGains[lastQID] = self.getIdealDCG(rel, self.k if len(rel) > self.k else len(rel))
 
     def copy(self):
         return NDCGScorer()
@@ -94,9 +132,16 @@ class DCGScorer(MetricScorer):        # metric/DCGScorer.java
         return dcg
 
 
-class APScorer(MetricScorer):         # metric/APScorer.java (K is ignored by score(); no external judgments)
+class APScorer(MetricScorer):         # metric/APScorer.java (K is ignored by score())
     def __init__(self):
         super().__init__(0)
+        self.relDocCount = None       # :33
+
+    def loadExternalRelevanceJudgment(self, qrelFile):     # :45-66
+        self.relDocCount = {}
+        for qid, label in _qrel_lines(qrelFile):
+            if label > 0:
+                self.relDocCount[qid] = self.relDocCount.get(qid, 0) + 1
 
     def copy(self):
         return APScorer()
@@ -110,7 +155,8 @@ class APScorer(MetricScorer):         # metric/APScorer.java (K is ignored by sc
             if rl.get(i).getLabel() > 0.0:
                 count += 1
                 ap += count / (i + 1)
-        return 0.0 if count == 0 else ap / count
+        rdCount = count if self.relDocCount is None else self.relDocCount.get(rl.getID(), 0)      # :86-94
+        return 0.0 if rdCount == 0 else ap / rdCount
 
 
 class ERRScorer(MetricScorer):        # metric/ERRScorer.java

@@ -96,6 +96,7 @@ def lib():
         L.ro_query_score.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         L.ro_eval_flat_model.argtypes = [C.c_int32, C.c_int32] + [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
         L.ro_set_err_max.argtypes = [C.c_double]
+        L.ro_set_external.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.ro_float_chain.restype = C.c_float
         L.ro_float_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         _lib = L
@@ -157,6 +158,11 @@ class Oracle:
                                  None if qk is None else qk.ctypes.data)
         self.nv = Xv.shape[0]
         self.has_valid = True
+
+    def set_external(self, validation, ideal=None, rel_count=None):
+        idl = None if ideal is None else np.ascontiguousarray(ideal, dtype=np.float64)
+        rdc = None if rel_count is None else np.ascontiguousarray(rel_count, dtype=np.int32)
+        self.L.ro_set_external(self.h, 1 if validation else 0, None if idl is None else idl.ctypes.data, None if rdc is None else rdc.ctypes.data)
 
     def init(self):
         self.L.ro_init(self.h)

@@ -843,3 +843,48 @@ def test_ensemble_eval_with_1200_trees_streams_many_lds_tiles():
     want = O.eval_flat_model([trees[i % 40] for i in range(1200)], rows, n_threads=8)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     m.close()
+
+
+# ---- -qrel: external relevance judgments (eval/Evaluator.java:580-591; NDCGScorer.java:50-96, APScorer.java:45-66, :86-94, :124-143) -------
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric,k", [("NDCG", 10), ("MAP", 0)])
+def test_external_relevance_judgments_match_the_oracle(metric, k):
+    """NDCG: lists whose qid has an idealGains entry from the judgment file never compute their own ideal DCG (some entries here are larger than
+    the list's own, one is 0: the list then scores 0 and gets no lambdas); MAP: rdCount comes from the file, 0 for qids that are not in it.
+    Training set AND validation set, lambdas / weights / trees / scores / both metrics against the oracle, early stopping included."""
+    rng = np.random.default_rng(77)
+    X, lab, qoff = synth.make_dataset(5000, 10, "mslr", seed_offset=91)
+    Xv, labv, qoffv = synth.make_dataset(2500, 10, "mslr", seed_offset=92)
+    Q, Qv = len(qoff) - 1, len(qoffv) - 1
+    ideal = idealv = rd = rdv = None
+    if metric == "NDCG":
+        ideal = np.where(rng.random(Q) < 0.6, 5.0 + 40.0 * rng.random(Q), np.nan); ideal[3] = 0.0
+        idealv = np.where(rng.random(Qv) < 0.5, 5.0 + 40.0 * rng.random(Qv), np.nan)
+    else:
+        rd = rng.integers(0, 60, Q).astype(np.int32); rd[rng.random(Q) < 0.2] = 0
+        rdv = rng.integers(0, 60, Qv).astype(np.int32)
+    o = O.Oracle(X, lab, qoff, n_trees=12, n_leaves=8, metric=metric, k=k, early_stop=3)
+    # strict mode: identical trees, so the validation rows take the same branches and the validation metric can be compared unconditionally
+    g = N.Trainer(n_trees=12, n_leaves=8, metric=metric, metric_k=k, early_stop_rounds=3, flags=N.RL_FLAG_JAVA_ORDER)
+    g.set_train(X, lab, qoff)
+    o.set_validation(Xv, labv, qoffv); g.set_validation(Xv, labv, qoffv)
+    o.set_external(False, ideal, rd); o.set_external(True, idealv, rdv)
+    g.set_external_judgments(False, ideal, rd); g.set_external_judgments(True, idealv, rdv)
+    o.init(); g.init()
+    for r in range(12):
+        to, tmo, vmo, so = o.round()
+        tg, tmg, vmg, sg = g.boost_round()
+        assert np.array_equal(g.array("LAMBDA").view(np.int64), o.lambdas().view(np.int64)), r
+        assert np.array_equal(g.array("WEIGHT").view(np.int64), o.weights().view(np.int64)), r
+        assert_equivalent(to, tg, X, ctx="round %d" % r)
+        assert np.array_equal(g.array("SCORE").view(np.int64), o.scores().view(np.int64)), r
+        assert np.float32(tmg).view(np.uint32) == np.float32(tmo).view(np.uint32) and np.float32(vmg).view(np.uint32) == np.float32(vmo).view(np.uint32), r
+        assert so == sg
+        if sg:
+            break
+    assert o.finish() == g.finish()
+    # and the judgments matter: the same run without them ends elsewhere
+    g2 = N.Trainer(n_trees=2, n_leaves=8, metric=metric, metric_k=k)
+    g2.set_train(X, lab, qoff); g2.init(); g2.boost_round()
+    o2 = O.Oracle(X, lab, qoff, n_trees=2, n_leaves=8, metric=metric, k=k); o2.set_external(False, ideal, rd); o2.init(); o2.round()
+    assert not np.array_equal(g2.array("LAMBDA"), o2.lambdas())

@@ -534,3 +534,60 @@ def test_cli_norm_trains_on_the_normalised_lists(tmp_path, kind):
     assert cli[cli.index("<ensemble>"):] == r.model()[r.model().index("<ensemble>"):]
     assert cli[cli.index("<ensemble>"):] != open(m_raw).read()[open(m_raw).read().index("<ensemble>"):]
     assert len(open(run).read().splitlines()) > 0
+
+
+# ---- -qrel ---------------------------------------------------------------------------------------------------------------------------
+def test_qrel_file_feeds_the_ndcg_cache_and_the_map_counts(tmp_path):
+    """metric/NDCGScorer.java:50-96 (one idealGains entry per RUN of equal qids, ideal DCG of ALL judged documents at min(k, #judged));
+    metric/APScorer.java:45-66, :86-94 (relDocCount per qid; a list whose qid is not in the file scores 0)"""
+    from ranklib_amd import metric as M
+    from ranklib_amd.learning import DataPoint as DP, RankList as RL
+    q = tmp_path / "qrels.txt"
+    q.write_text("q1 0 d1 2\nq1 0 d2 0\nq1 0 d3 1.6\n\nq2 0 d1 0\nq2 0 d9 3\nq1 0 d7 1\n")
+    nd = M.NDCGScorer(2)
+    nd.loadExternalRelevanceJudgment(str(q))
+    assert nd.idealGains["q2"] == M.gain(3) * M.discount(0) + M.gain(0) * M.discount(1)
+    assert nd.idealGains["q1"] == M.gain(1) * M.discount(0)              # the later run of q1 (one document) overwrote the first
+    ap = M.APScorer()
+    ap.loadExternalRelevanceJudgment(str(q))
+    assert ap.relDocCount == {"q1": 3, "q2": 1}                          # rint(1.6) = 2 > 0 counts
+    mk = lambda qid, labels: RL([DP.from_parsed(float(l), qid, "", np.array([np.nan, 1.0], np.float32)) for l in labels])   # noqa: E731
+    assert ap.score(mk("q1", [1, 0, 1])) == (1.0 / 1 + 2.0 / 3) / 3      # three relevant documents judged, two retrieved
+    assert ap.score(mk("zz", [1, 1])) == 0.0                             # qid not in the file: rdCount stays 0
+    assert M.APScorer().score(mk("zz", [1, 1])) == 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m2t", ["NDCG@10", "MAP"])
+def test_cli_qrel_reaches_the_trainer(tmp_path, m2t):
+    """-qrel <file> (eval/Evaluator.java:243-244, :580-591): the saved model differs from the one trained without the judgments and equals
+    the one trained through the API with a scorer that loaded the same file"""
+    from ranklib_amd.features import FeatureManager
+    from ranklib_amd.metric import MetricScorerFactory
+    data, qrel, m_q, m_raw = (str(tmp_path / n) for n in ("data.txt", "qrels.txt", "q.txt", "raw.txt"))
+    rng = np.random.RandomState(11)
+    with open(data, "w") as f:
+        for q in range(40):
+            for d in range(int(rng.randint(4, 15))):
+                x = rng.rand(4)
+                f.write("%d qid:%d 1:%f 2:%f 3:%f 4:%f # d%d_%d\n" % (int(3 * x[0] * x[1] + rng.rand()), q, x[0], x[1], x[2], x[3], q, d))
+    lists = FeatureManager.readInput(data)
+    with open(qrel, "w") as f:            # judgments for two thirds of the queries: more relevant documents than the lists retrieved
+        for rl in lists[: 2 * len(lists) // 3]:
+            for d in range(rl.size() + 5):
+                f.write("%s 0 doc%d %d\n" % (rl.getID(), d, int(rng.randint(0, 5))))
+    saved = (learning.LambdaMART.nTrees, learning.LambdaMART.nTreeLeaves)
+    try:
+        evaluator.main(["-train", data, "-ranker", "6", "-metric2t", m2t, "-tree", "5", "-leaf", "6", "-qrel", qrel, "-save", m_q])
+        evaluator.main(["-train", data, "-ranker", "6", "-metric2t", m2t, "-tree", "5", "-leaf", "6", "-save", m_raw])
+        assert evaluator.Evaluator.qrelFile == ""
+        learning.LambdaMART.nTrees, learning.LambdaMART.nTreeLeaves = 5, 6
+        sc = MetricScorerFactory().createScorer(m2t)
+        sc.loadExternalRelevanceJudgment(qrel)
+        feats = FeatureManager.getFeatureFromSampleVector(lists)
+        r = learning.RankerTrainer().train(learning.RankerType.LAMBDAMART, lists, feats, sc)
+    finally:
+        learning.LambdaMART.nTrees, learning.LambdaMART.nTreeLeaves = saved
+    cli, raw = open(m_q).read(), open(m_raw).read()
+    assert cli[cli.index("<ensemble>"):] == r.model()[r.model().index("<ensemble>"):]
+    assert cli[cli.index("<ensemble>"):] != raw[raw.index("<ensemble>"):]
