@@ -14,6 +14,8 @@ final class RlHipNative {
             int[] featureIds, int[] qkey);
     /** a block of rows after setData(.., X = null, ..): X holds nDocs * nFeatures floats from position 0 (rlhip.h rl_set_rows) */
     static native int setRows(long h, boolean validation, long firstDoc, long nDocs, FloatBuffer X);
+    /** -qrel: per ranked list, its qid's idealGains entry (NaN = none) / relDocCount (0 = qid not in the file); either may be null (rlhip.h rl_set_external_judgments) */
+    static native int setExternalJudgments(long h, boolean validation, double[] idealDcg, int[] relDocCount);
     static native int init(long h);
     static native int boostRound(long h, int[] feature, float[] threshold, int[] left, int[] right, float[] output, float[] metrics);
     static native double[] finish(long h);

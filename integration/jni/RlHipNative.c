@@ -69,6 +69,19 @@ JNIEXPORT jint JNICALL Java_ciir_umass_edu_learning_tree_RlHipNative_setRows(JNI
     return 0;
 }
 
+/* -qrel: what a scorer that loaded an external judgment file holds, resolved per ranked list by the caller */
+JNIEXPORT jint JNICALL Java_ciir_umass_edu_learning_tree_RlHipNative_setExternalJudgments(JNIEnv *env, jclass c, jlong h, jboolean validation,
+        jdoubleArray idealDcg, jintArray relDocCount)
+{
+    jdouble *idl = idealDcg ? (*env)->GetDoubleArrayElements(env, idealDcg, NULL) : NULL;
+    jint *rdc = relDocCount ? (*env)->GetIntArrayElements(env, relDocCount, NULL) : NULL;
+    const int rc = rl_set_external_judgments((rl_trainer *)(intptr_t)h, validation ? 1 : 0, idl, (const int32_t *)rdc);
+    if (idl) (*env)->ReleaseDoubleArrayElements(env, idealDcg, idl, JNI_ABORT);
+    if (rdc) (*env)->ReleaseIntArrayElements(env, relDocCount, rdc, JNI_ABORT);
+    CHECK(rc);
+    return 0;
+}
+
 JNIEXPORT jint JNICALL Java_ciir_umass_edu_learning_tree_RlHipNative_init(JNIEnv *env, jclass c, jlong h)
 { CHECK(rl_init((rl_trainer *)(intptr_t)h)); return 0; }
 

@@ -36,6 +36,8 @@ struct JNINativeInterface_ {
     jdoubleArray (*NewDoubleArray)(JNIEnv *env, jsize len);
     jint *(*GetIntArrayElements)(JNIEnv *env, jintArray array, jboolean *isCopy);
     jfloat *(*GetFloatArrayElements)(JNIEnv *env, jfloatArray array, jboolean *isCopy);
+    jdouble *(*GetDoubleArrayElements)(JNIEnv *env, jdoubleArray array, jboolean *isCopy);
+    void (*ReleaseDoubleArrayElements)(JNIEnv *env, jdoubleArray array, jdouble *elems, jint mode);
     void (*ReleaseIntArrayElements)(JNIEnv *env, jintArray array, jint *elems, jint mode);
     void (*ReleaseFloatArrayElements)(JNIEnv *env, jfloatArray array, jfloat *elems, jint mode);
     void (*SetFloatArrayRegion)(JNIEnv *env, jfloatArray array, jsize start, jsize len, const jfloat *buf);
