@@ -256,6 +256,8 @@ def main(argv=None):
         elif a == "-kcvmd": kcvModelDir = nxt()
         elif a == "-kcvmn": kcvModelFile = nxt()
         elif a == "-qrel": Evaluator.qrelFile = nxt()       # :243-244
+        elif a in ("-nf", "-t"): nxt()                      # :359-364: newFeatureFile / topNew, statics that nothing in the reference reads
+        elif a == "-keep": pass                             # keepOrigFeatures, likewise
         elif a == "-norm":                                   # :256-267
             Evaluator.nml = normalizer.create(nxt())
             Evaluator.normalize = True
