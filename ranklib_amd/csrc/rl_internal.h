@@ -117,6 +117,8 @@ struct Ctx {
     int32_t dm_root, dm_div;   // document-major rows for the root pass (0 / 1); for a node of cnt samples when cnt * dm_div <= N (0 = never, 1 = every child)
     int32_t sub;            // features of a group handled per histogram block (kHistFG unless the threshold table is huge)
     const int32_t *mode;    // [F] most populated bin of every feature: never accumulated, rebuilt as total - others
+    const uint32_t *runs;   // [numFG] bit j: feature 16 g + j comes in runs of equal bins (query-level columns): quad-folded atomics in k_hist<.., RUNS>
+    int32_t any_runs;       // some column does: the RUNS instantiation of k_hist is launched
     const float *thr;       // [F][TS]
     const int32_t *nthr;    // [F]
     const int32_t *feature_ids;

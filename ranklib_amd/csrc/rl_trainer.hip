@@ -400,7 +400,11 @@ template <bool ROOT>
 static void launch_hist(const Ctx &c, int gx, int gy, size_t lds, hipStream_t s)
 {
     const dim3 g(gx, (gy + 7) & ~7), b(kThreads);      // the XCD-aware block map of k_hist wants a multiple of 8 chunks (the extra blocks exit)
-    if (c.sub == 16 && c.TS <= kHistLdsStride) { hipLaunchKernelGGL((k_hist<ROOT, 16, kHistLdsStride>), g, b, lds, s, c); return; }
+    if (c.sub == 16 && c.TS <= kHistLdsStride) {
+        if (c.any_runs) hipLaunchKernelGGL((k_hist<ROOT, 16, kHistLdsStride, true>), g, b, lds, s, c);
+        else hipLaunchKernelGGL((k_hist<ROOT, 16, kHistLdsStride>), g, b, lds, s, c);
+        return;
+    }
     switch (c.sub) {
     case 16: hipLaunchKernelGGL((k_hist<ROOT, 16, 0>), g, b, lds, s, c); break;
     case 8: hipLaunchKernelGGL((k_hist<ROOT, 8, 0>), g, b, lds, s, c); break;
@@ -809,6 +813,8 @@ int rl_create(const rl_params *p, rl_trainer **out)
     RL_HIP(hipEventCreateWithFlags(&t->ev_ranked, hipEventDisableTiming)); RL_HIP(hipEventCreateWithFlags(&t->ev_metric, hipEventDisableTiming));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 16, kHistLdsStride>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 16, kHistLdsStride>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 16, kHistLdsStride, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 16, kHistLdsStride, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
@@ -1063,6 +1069,24 @@ int rl_init(rl_trainer *t)
     RL_HIP(t->pool.alloc(&d_mode, (size_t)F));
     c.mode = d_mode;
     hipLaunchKernelGGL(k_cumulate_counts, dim3(F), dim3(64), 0, s, TS, (const int32_t *)d_nthr, c.cum_cnt, d_mode);
+    {   // columns whose bins come in runs (nine in ten documents outside the mode bin are followed by an equal bin: a quad agrees 3 times in 4)
+        unsigned long long *d_rs = nullptr;
+        RL_HIP(t->pool.alloc(&d_rs, (size_t)2 * F));
+        hipLaunchKernelGGL(k_run_stats, dim3(F), dim3(kThreads), 0, s, (const uint16_t *)d_bins, (const int32_t *)d_mode, N, Npad, d_rs);
+        std::vector<unsigned long long> h_rs((size_t)2 * F);
+        RL_HIP(hipMemcpyAsync(h_rs.data(), d_rs, h_rs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        RL_HIP(hipStreamSynchronize(s));
+        t->pool.release(d_rs);
+        std::vector<uint32_t> h_runs((size_t)c.numFG, 0u);
+        const bool runs_on = !getenv("RLHIP_RUNS_OFF") && c.sub == 16 && TS <= kHistLdsStride;      // the instantiation that exists
+        c.any_runs = 0;
+        for (int f = 0; f < F && runs_on; f++)
+            if (h_rs[2 * f] >= 64 && 10 * h_rs[2 * f + 1] >= 9 * h_rs[2 * f]) { h_runs[f / kHistFG] |= 1u << (f % kHistFG); c.any_runs = 1; }
+        uint32_t *d_runs = nullptr;
+        RL_HIP(t->pool.alloc(&d_runs, h_runs.size()));
+        RL_HIP(hipMemcpy(d_runs, h_runs.data(), h_runs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c.runs = d_runs;
+    }
     RL_HIP(hipGetLastError());
     RL_HIP(hipStreamSynchronize(s));
     t->pool.release(Xt); t->pool.release(thr0); t->pool.release(fs.set);

@@ -888,3 +888,41 @@ def test_external_relevance_judgments_match_the_oracle(metric, k):
     g2.set_train(X, lab, qoff); g2.init(); g2.boost_round()
     o2 = O.Oracle(X, lab, qoff, n_trees=2, n_leaves=8, metric=metric, k=k); o2.set_external(False, ideal, rd); o2.init(); o2.round()
     assert not np.array_equal(g2.array("LAMBDA"), o2.lambdas())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_docs,n_qlevel,leaves", [(9001, 5, 12), (30011, 11, 31)])
+def test_query_level_columns_take_the_quad_folded_histogram_path(n_docs, n_qlevel, leaves, monkeypatch):
+    """columns that hold one value per query come in runs of equal bins: rl_init flags them (k_run_stats) and k_hist<.., RUNS> folds the four
+    samples of a quad that agree into one LDS atomic (DPP quad permutes).  Integer sums, so nothing may change: histograms, trees, scores
+    against the oracle, and against the same run with the path switched off (RLHIP_RUNS_OFF)."""
+    rng = np.random.default_rng(n_docs)
+    X, lab, qoff = synth.make_dataset(n_docs, 24, "mslr", seed_offset=33)
+    X = X.copy()
+    nq = len(qoff) - 1
+    for j in range(n_qlevel):           # query-level columns, some with few distinct values (one of them becomes the mode bin), spread over both groups
+        vals = rng.random(nq).astype(np.float32) if j % 2 else np.floor(rng.random(nq) * 3).astype(np.float32)
+        X[:, 2 * j + 1] = np.repeat(vals, np.diff(qoff))
+    runs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("RLHIP_RUNS_OFF", "1")
+        g = N.Trainer(n_trees=4, n_leaves=leaves)
+        g.set_train(X, lab, qoff)
+        g.init()
+        rec = []
+        for _ in range(4):
+            t, tm, _, _ = g.boost_round()
+            rec.append((t.trimmed(), g.array("SCORE").copy(), tm))
+        runs.append(rec)
+    o = O.Oracle(X, lab, qoff, n_trees=4, n_leaves=leaves, n_threads=4)
+    o.init()
+    for r in range(4):
+        to, tmo, _, _ = o.round()
+        for rec in runs:
+            assert np.array_equal(rec[r][1].view(np.int64), o.scores().view(np.int64)), r
+            assert np.float32(rec[r][2]).view(np.uint32) == np.float32(tmo).view(np.uint32)
+        for key in ("feature", "left", "right", "count"):
+            assert np.array_equal(runs[0][r][0][key], runs[1][r][0][key]), (r, key)
+        assert np.array_equal(runs[0][r][0]["threshold"].view(np.uint32), runs[1][r][0]["threshold"].view(np.uint32))
+        assert np.array_equal(runs[0][r][0]["deviance"].view(np.int64), runs[1][r][0]["deviance"].view(np.int64))      # exact fixed-point sums either way
