@@ -19,7 +19,7 @@ for k in ks:
     for f in range(k):
         vals = rng.random(len(qoff) - 1).astype(np.float32)
         X[:, 4 * f + 1] = np.repeat(vals, np.diff(qoff))
-    g = N.Trainer(n_trees=40, n_leaves=31, flags=N.RL_FLAG_TIMING)
+    g = N.Trainer(n_trees=40, n_leaves=31, flags=N.RL_FLAG_TIMING | N.RL_FLAG_TIMING_NODES)
     g.set_train(X, lab, qoff)
     g.init()
     g.boost_rounds_async(5); g.sync(); g.reset_timing()
