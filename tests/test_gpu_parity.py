@@ -926,3 +926,23 @@ def test_query_level_columns_take_the_quad_folded_histogram_path(n_docs, n_qleve
             assert np.array_equal(runs[0][r][0][key], runs[1][r][0][key]), (r, key)
         assert np.array_equal(runs[0][r][0]["threshold"].view(np.uint32), runs[1][r][0]["threshold"].view(np.uint32))
         assert np.array_equal(runs[0][r][0]["deviance"].view(np.int64), runs[1][r][0]["deviance"].view(np.int64))      # exact fixed-point sums either way
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F,n,leaves", [(3000, 4000, 15), (136, 8000, 128), (17, 20000, 300)])
+def test_wide_and_deep_shapes_match_the_oracle(F, n, leaves):
+    """thousands of columns (188 feature groups; the growth bookkeeping's per-feature reductions) and hundreds of leaves (node records beyond
+    the LDS copy, the serial queue of select_step): lambdas and scores bit for bit, trees equivalent"""
+    X, lab, qoff = synth.make_dataset(n, F, "mslr", seed_offset=5)
+    g = N.Trainer(n_trees=3, n_leaves=leaves)
+    g.set_train(X, lab, qoff)
+    g.init()
+    o = O.Oracle(X, lab, qoff, n_trees=3, n_leaves=leaves, n_threads=os.cpu_count() or 8)
+    o.init()
+    for r in range(3):
+        to, tmo, _, _ = o.round()
+        tg, tmg, _, _ = g.boost_round()
+        assert np.array_equal(g.array("LAMBDA"), o.lambdas())
+        assert_equivalent(to, tg, X, "round %d" % r)
+        assert np.array_equal(g.array("SCORE").view(np.int64), o.scores().view(np.int64)), r
+        assert np.float32(tmg).view(np.uint32) == np.float32(tmo).view(np.uint32)
