@@ -124,6 +124,10 @@ for case in range(n_cases):
     X[:, ::3] = np.floor(X[:, ::3] * rng.integers(2, 30))                  # low-cardinality columns, ties
     if F > 8:
         X[:, 5] = 0.0                                                       # a dead column
+    if rng.random() < 0.3:                                                  # query-level columns (one value per list): k_hist<.., RUNS>
+        for f in rng.choice(F, size=min(F, int(rng.integers(1, 4))), replace=False):
+            vals = rng.random(len(sizes)).astype(np.float32) if rng.random() < 0.5 else np.floor(rng.random(len(sizes)) * 4).astype(np.float32)
+            X[:, f] = np.repeat(vals, sizes)
     z = X[:, 0] * 0.3 + X[:, 1 % F] * X[:, 2 % F] + 0.5 * rng.random(n)
     lab = np.floor(np.clip(z / z.max() * 5, 0, 4)).astype(np.float32)
     ranker = rng.choice(["LAMBDAMART", "LAMBDAMART", "MART"])
