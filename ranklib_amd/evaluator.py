@@ -197,7 +197,7 @@ def main(argv=None):
     logging.basicConfig(level=logging.INFO, format="%(message)s")
     if not args:
         print("Usage: -train <file> -ranker 6|0|8 [-bag n -srate f -frate f -rtype 0|6 -seed n] [-metric2t NDCG@k|DCG@k|MAP|ERR@k] [-tree n] [-leaf n] [-shrinkage f] [-tc n] [-mls n] [-estop n] "
-              "[-validate f] [-test f] [-feature f] [-save model] | -load model [-test f] [-rank f -indri out] [-score out]")
+              "[-validate f] [-test f] [-feature f] [-norm sum|zscore|linear] [-qrel f] [-gmax g] [-save model] | -load model [-test f] [-rank f -indri out] [-score out]")
         return 0
     trainFile = validationFile = testFile = featureDescriptionFile = savedModelFile = rankFile = indriRankingFile = scoreFile = modelFile = prpFile = ""
     Evaluator.mustHaveRelDoc = False
