@@ -11,8 +11,9 @@ features, ~31.5 k queries, 31 leaves); it fits one GPU, so N = 1 runs the whole 
 set's queries contiguously over the ranks ("scaling": "strong"; one exact histogram all-reduce per split over
 RCCL).  `--shape c1` runs configs[1] (MSLR-WEB10K-shape, 1.2 M documents).
 
-  python bench.py --gpus 1 --steps K --warmup W
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...    (queries sharded by rank)
+  python bench.py --gpus N --steps K --warmup W      N > 1: the script starts its own N ranks (torch.distributed.run, one per GPU)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...    (the same, launched from outside)
+  --scaling weak: N x the shape's documents (the same documents per rank at every N) instead of the same set sharded
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the root histogram, rl::k_hist<true>):
 algorithmic bytes per launch / HIP-event time of that launch measured live on the library's own stream.
@@ -90,6 +91,8 @@ def bench_infer(args):
     from ranklib_amd import synth
     # N > 1 (torch.distributed.run): independent replicas, every rank scores its own `--docs` rows with the same model ("scaling": "weak";
     # there is nothing to exchange in Ensemble.eval).  gloo only carries the barrier and the max of the elapsed times.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return respawn(args.gpus)
     world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
@@ -196,6 +199,20 @@ def bench_infer(args):
     print(json.dumps(out))
 
 
+def respawn(n):
+    """`python bench.py --gpus N` as typed: re-exec this script as N ranks (one per GPU) under torch.distributed.run on a free local port.
+    Rank 0 prints the one JSON line; stdout / stderr / exit code are the launcher's."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execvpe(sys.executable, cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,12 +229,15 @@ def main():
     ap.add_argument("--metric", default="NDCG", help="train metric: NDCG (the BASELINE.json metric) | DCG | ERR | MAP (RankLib's own default is ERR@10)")
     ap.add_argument("--java-order", action="store_true", help="RL_FLAG_JAVA_ORDER: the strict mode (split gains from the Java's own f64 summation order)")
     ap.add_argument("--workload", default="train", help="train (default, the BASELINE.json metric) | infer (configs[4]: Ensemble.eval)")
+    ap.add_argument("--scaling", default="strong", help="strong (default: the SAME data set sharded over --gpus ranks, what BASELINE.json configs[2] states) | "
+                                                       "weak (--gpus x the shape's documents: the same documents per rank at every N)")
+    ap.add_argument("--c1-trees", type=int, default=1000, help="after the headline run: BASELINE.json configs[1] as stated (c1 shape, this many trees) -> config.c1_full_run (0 = skip; N = 1 only)")
     ap.add_argument("--trees", type=int, default=10000, help="infer: trees in the scored model")
     ap.add_argument("--docs", type=int, default=100000000, help="infer: rows per GPU and step (configs[4]: 100 M = 54.8 GB of rows in HBM)")
     ap.add_argument("--infer-train-rounds", type=int, default=100)
     args = ap.parse_args()
     if args.plain:
-        args.cpu_rounds, args.sustain, args.node_rounds, args.no_pmc, args.no_timing = 0, 0, 0, True, True
+        args.cpu_rounds, args.sustain, args.node_rounds, args.no_pmc, args.no_timing, args.c1_trees = 0, 0, 0, True, True, 0
     if args.workload == "infer":
         if not any(a.startswith("--steps") for a in sys.argv):
             args.steps, args.warmup = 3, 1
@@ -233,9 +253,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("RLHIP_BENCH_SAME_GPU"):        # debugging aid: several ranks on one device (RCCL may refuse this)
         local_rank = 0
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return respawn(args.gpus)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: run `python bench.py --gpus N` (it starts its own ranks) or launch N ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -247,6 +268,9 @@ def main():
         dist.init_process_group("gloo")
 
     n_docs, n_feat, kind, n_trees, n_leaves = synth.SHAPES[args.shape]
+    weak = args.scaling == "weak"
+    if weak:
+        n_docs *= world         # the same documents per rank at every N
     t0 = time.time()
     X, lab, qoff, q_total = synth.make_shard(n_docs, n_feat, kind, rank, world)
     t_gen = time.time() - t0
@@ -266,7 +290,7 @@ def main():
             # RCCL refuses duplicate devices -- exercises this script's N > 1 path, not the interconnect
             from ranklib_amd import dist as D
             tr = D.TorchHostTransport()
-            g.dist_init_callback(rank, world, tr.allreduce, tr.allgather)
+            g.dist_init_callback(rank, world, tr.allreduce, tr.allgather, tr.alltoallv)
         else:
             box = [g.dist_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
@@ -337,16 +361,18 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": "weak" if weak else "strong",
         "vs_baseline": None,
         "dtype": "int64 fixed-point histograms + f64 lambdas/scores (f32 leaf chains as in the Java)",
         "data": "synthetic",
         "config": {
-            "workload": "%s: synthetic %s, %d docs x %d features, %d queries (%s docs/query) in total, queries sharded "
+            "workload": "%s%s: synthetic %s, %d docs x %d features, %d queries (%s docs/query) in total, queries sharded "
                         "contiguously over %d GPU(s); LambdaMART -ranker 6, %d leaves, lr 0.1, -tc 256, -mls 1, NDCG@10" %
-                        (args.shape, {"c2": "MSLR-WEB30K-shape (BASELINE.json configs[2], the shape the metric is quoted on)",
-                                      "c1": "MSLR-WEB10K-shape (BASELINE.json configs[1])"}.get(args.shape, args.shape),
+                        (args.shape, (" x %d (weak scaling: %d documents per GPU at every N)" % (world, n_docs // world)) if weak else "",
+                         {"c2": "MSLR-WEB30K-shape (BASELINE.json configs[2], the shape the metric is quoted on)",
+                          "c1": "MSLR-WEB10K-shape (BASELINE.json configs[1])"}.get(args.shape, args.shape),
                          n_docs, n_feat, q_total, "~120 log-normal" if kind == "mslr" else "5..15", world, n_leaves),
+            "document_rounds_per_s": n_docs * rounds_per_s,      # the figure that aggregates over ranks under weak scaling
             "docs_total": n_docs, "docs_rank0": int(X.shape[0]), "features": n_feat, "queries_total": q_total, "leaves": n_leaves,
             "ndcg10_train_after_%d_rounds" % total_rounds: ndcg_t,
             "init_seconds": round(t_init, 3), "datagen_seconds": round(t_gen, 3),
@@ -413,7 +439,14 @@ def main():
                                       "hist_nodes": node["ms_per_round"] if node else None}
     if world > 1:
         out["config"]["exchange_per_round_rank0"] = {"allreduce_calls": ds[0], "allreduce_bytes": ds[1], "allgather_calls": ds[2], "allgather_bytes_received": ds[3],
-                                                     "note": "payload sizes handed to RCCL by this rank (histogram limbs per growth step; lambda / weight of the leaves; per-query metric values)"}
+                                                     "alltoall_calls": ds[4], "alltoall_bytes_received": ds[5],
+                                                     "allgather_of_every_lambda_would_be_bytes": 16.0 * n_docs,
+                                                     "transport": "host callbacks over gloo (test aid)" if os.environ.get("RLHIP_BENCH_TRANSPORT") == "gloo" else "RCCL",
+                                                     "note": "payload handed to the transport by this rank per round: histogram limbs per growth step (all-reduce); lambda / weight of the "
+                                                             "leaves this rank owns, from the ranks that hold their documents (all-to-all); per-query metric values and leaf tables (all-gather)"}
+        if not weak:
+            out["config"]["scaling_note"] = ("strong scaling of %d documents is latency-bound: a 31-leaf tree is a chain of ~11 dependent growth steps, each with one "
+                                             "all-reduce when sharded, whatever the shard size (DESIGN.md 6); --scaling weak keeps the documents per GPU fixed" % n_docs)
     if sustained is not None:
         out["config"]["sustained_rounds_per_s"] = sustained
         out["config"]["sustained_over_rounds"] = args.sustain

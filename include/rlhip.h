@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define RLHIP_ABI_VERSION 3
+#define RLHIP_ABI_VERSION 4
 
 enum {
     RL_OK = 0,
@@ -61,8 +61,8 @@ enum { RL_METRIC_NDCG = 0, RL_METRIC_DCG = 1, RL_METRIC_MAP = 2, RL_METRIC_ERR =
 enum { RL_RANKER_MART = 0, RL_RANKER_LAMBDAMART = 6 };
 
 enum {                                  /* rl_params.flags */
-    RL_FLAG_FAST_LEAF = 1,              /* leaf sums as exact-f64 tree sums instead of emulating the Java float
-                                           running sums (learning/tree/LambdaMART.java:401-408).  NOT parity. */
+                                        /* bit 0 is reserved (rl_create rejects it): leaf outputs are always the Java's float running sums
+                                           (learning/tree/LambdaMART.java:401-408); there is no non-parity shortcut */
     RL_FLAG_TIMING = 2,                 /* record HIP events around the root histogram and the lambda kernels (rl_get_timing) */
     RL_FLAG_TIMING_NODES = 8,           /* ... and around every growth step's node-histogram launch (30 event pairs per round) */
     RL_FLAG_SERIAL_CHAIN = 4,           /* evaluate the float running sums with the literal serial kernel instead of
@@ -153,7 +153,7 @@ int rl_set_rows(rl_trainer *t, int32_t validation, int64_t first_doc, int64_t n_
  *                     in the file.  NULL = no external ideal gains.
  *   rel_doc_count[Q]  MAP: relDocCount of the list's qid (metric/APScorer.java:45-66), 0 when the qid is not in the file (the Java then scores
  *                     the list 0 and returns all-zero swap changes, :86-94, :124-143).  NULL = every list counts its own relevant documents.
- * After rl_set_train / rl_set_validation of that data set, before rl_init.  Single GPU. */
+ * After rl_set_train / rl_set_validation of that data set, before rl_init.  Sharded runs: every rank passes the entries of ITS lists. */
 int rl_set_external_judgments(rl_trainer *t, int32_t validation, const double *ideal_dcg, const int32_t *rel_doc_count);
 
 int rl_init(rl_trainer *t);
@@ -174,6 +174,9 @@ int rl_sync(rl_trainer *t);
 int rl_finish(rl_trainer *t, double *train_score, double *valid_score);
 
 int rl_num_trees(const rl_trainer *t, int32_t *n);
+/* Nodes the largest possible tree of this trainer has = the `cap` of an rl_tree that always suffices, known after rl_init: 2 * n_leaves - 1, at
+ * least 3 (the root is split unconditionally, RegressionTree.java:62-67); with -leaf -1 (n_leaves == -1) 2 * floor(N / min_leaf_support) - 1. */
+int rl_tree_capacity(const rl_trainer *t, int32_t *cap);
 int rl_get_tree(const rl_trainer *t, int32_t i, rl_tree *out);
 int rl_get_round_metrics(const rl_trainer *t, int32_t round, float *train_metric, float *valid_metric);
 int rl_best_validation(const rl_trainer *t, int32_t *best_round, double *best_score);
@@ -226,8 +229,9 @@ int rl_dist_unique_id(void *id_out /* RL_UNIQUE_ID_BYTES */);       /* call on r
  * are summed across ranks with RCCL, per-query metric values are gathered in rank order. */
 int rl_dist_init(rl_trainer *t, const void *id, int32_t rank, int32_t n_ranks);
 
-/* Exchange volume of this rank since rl_dist_init: out[0..3] = all-reduce calls, all-reduce payload bytes, all-gather calls, all-gather
- * bytes received (zeros for an unsharded trainer).  bench.py prints the per-round figures for N > 1. */
+/* Exchange volume of this rank since rl_dist_init: out[0..5] = all-reduce calls, all-reduce payload bytes, all-gather calls, all-gather
+ * bytes received, all-to-all calls, all-to-all bytes received from OTHER ranks (zeros for an unsharded trainer).  bench.py prints the
+ * per-round figures for N > 1. */
 int rl_dist_stats(const rl_trainer *t, int64_t *out);
 
 /* The same sharded training over a caller-supplied transport instead of RCCL (gloo, MPI, shared memory ...):
@@ -239,8 +243,13 @@ enum { RL_DT_I64 = 0, RL_DT_U64 = 1, RL_DT_I32 = 2, RL_DT_U32 = 3, RL_DT_F64 = 4
 enum { RL_OP_SUM = 0, RL_OP_MAX = 1, RL_OP_MIN = 2 };
 typedef int (*rl_host_allreduce_fn)(void *user, void *host_buf, int64_t count, int32_t dtype, int32_t op);
 typedef int (*rl_host_allgather_fn)(void *user, const void *in, void *out, int64_t bytes_per_rank);
+/* variable all-to-all in BYTES: rank p receives send[sdispl[p] .. +scount[p]) of this rank; what rank p sends to this rank lands at
+ * recv[rdispl[p] .. +rcount[p]) (p == own rank included: a plain copy).  All four arrays have n_ranks entries. */
+typedef int (*rl_host_alltoallv_fn)(void *user, const void *send, const int64_t *scount, const int64_t *sdispl, void *recv,
+                                    const int64_t *rcount, const int64_t *rdispl);
+/* alltoallv may be NULL: the leaf exchange is then emulated with all-gathers of whole send buffers (correct, R times the bytes). */
 int rl_dist_init_callback(rl_trainer *t, int32_t rank, int32_t n_ranks, rl_host_allreduce_fn allreduce,
-                          rl_host_allgather_fn allgather, void *user);
+                          rl_host_allgather_fn allgather, rl_host_alltoallv_fn alltoallv, void *user);
 
 /* ---- introspection for parity tests and the roofline report ------------------------------- */
 enum {
@@ -268,6 +277,10 @@ enum {
                                    SURVEY.md 8d times N), committed split nodes (nu times N) */
     RL_ARR_SPARSE_INFO = 19,    /* int64[4]: 16-feature groups whose root histogram comes from sparse-column entry lists (rl_csc.inc), entries,
                                    groups read as dense rows, live columns in the sparse groups */
+    RL_ARR_STEP_LOG = 20,       /* int32[8 + 8 * 8192], only with RLHIP_STEPLOG=1 in the environment of rl_init (else zeros): [0] = entries written; entry e at
+                                   8 + 8 e: {tree, 0, growth step, slot, documents of the split node, documents of the accumulated child, tie flag, slots of the
+                                   step} or {tree, 1, tie kind (1 = thresholds of one feature, 2 = several features), right child?, documents, largest node of
+                                   the Java-order derivation chain, nodes in the chain, documents in the chain} for a committed split whose best candidate was tied */
     RL_ARR_PHASE_CLOCKS = 16    /* int64[64][16] device wall-clock stamps (10 ns) inside the last 64 growth steps; all zero unless the
                                    library was built with -DRL_PHASE_CLOCKS (tools/phase_clocks.py) */
 };

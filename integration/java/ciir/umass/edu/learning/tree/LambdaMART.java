@@ -11,7 +11,10 @@ import java.util.logging.Logger;
 import ciir.umass.edu.learning.DataPoint;
 import ciir.umass.edu.learning.RankList;
 import ciir.umass.edu.learning.Ranker;
+import ciir.umass.edu.metric.APScorer;
+import ciir.umass.edu.metric.ERRScorer;
 import ciir.umass.edu.metric.MetricScorer;
+import ciir.umass.edu.metric.NDCGScorer;
 import ciir.umass.edu.parsing.ModelLineProducer;
 import ciir.umass.edu.utilities.RankLibError;
 import ciir.umass.edu.utilities.SimpleMath;
@@ -89,19 +92,54 @@ public class LambdaMART extends Ranker {
         if (inBlock > 0) RlHipNative.setRows(handle, validation, first, inBlock, X);
     }
 
+    /** a protected field of a RankLib scorer (NDCGScorer.idealGains, APScorer.relDocCount: metric/NDCGScorer.java:32, metric/APScorer.java:33) */
+    private static Object scorerField(final Object scorer, final Class<?> owner, final String name) {
+        try {
+            final java.lang.reflect.Field f = owner.getDeclaredField(name);
+            f.setAccessible(true);
+            return f.get(scorer);
+        } catch (final ReflectiveOperationException | RuntimeException e) {
+            throw RankLibError.create("rlhip: cannot read " + owner.getSimpleName() + "." + name + " (needed for -qrel); add a getter or open the package", e);
+        }
+    }
+
+    /** -qrel (eval/Evaluator.java:243-244, :580-591): whatever the scorer holds per qid when training starts is what the reference's
+     *  swapChange / score would find in it -- NDCG: idealGains entries (the external file's, and entries an earlier fold cached,
+     *  metric/NDCGScorer.java:114-122,134-143); MAP: relDocCount of the judgment file, 0 for a qid that is not in it (metric/APScorer.java:86-94,124-143). */
+    @SuppressWarnings("unchecked")
+    private void forwardJudgments(final List<RankList> lists, final boolean validation) {
+        if (scorer instanceof NDCGScorer) {
+            final Map<String, Double> ig = (Map<String, Double>) scorerField(scorer, NDCGScorer.class, "idealGains");
+            if (ig != null && !ig.isEmpty()) {
+                final double[] ideal = new double[lists.size()];
+                for (int q = 0; q < ideal.length; q++) { final Double d = ig.get(lists.get(q).getID()); ideal[q] = d == null ? Double.NaN : d; }
+                RlHipNative.setExternalJudgments(handle, validation, ideal, null);
+            }
+        } else if (scorer instanceof APScorer) {
+            final Map<String, Integer> rdc = (Map<String, Integer>) scorerField(scorer, APScorer.class, "relDocCount");
+            if (rdc != null) {
+                final int[] cnt = new int[lists.size()];
+                for (int q = 0; q < cnt.length; q++) { final Integer it = rdc.get(lists.get(q).getID()); cnt[q] = it == null ? 0 : it; }
+                RlHipNative.setExternalJudgments(handle, validation, null, cnt);
+            }
+        }
+    }
+
     @Override
     public void init() {
         logger.info(() -> "Initializing... ");
         final String mname = scorer.name().split("@")[0];                  // "NDCG@10" -> "NDCG", "MAP" -> "MAP"
         final int metric = "NDCG".equals(mname) ? 0 : "DCG".equals(mname) ? 1 : "MAP".equals(mname) ? 2 : "ERR".equals(mname) ? 3 : -1;
         if (metric < 0) throw RankLibError.create("rlhip: the train metric must be NDCG, DCG, MAP or ERR (got " + scorer.name() + ")");
+        RlHipNative.setErrMax(ERRScorer.MAX);                                // -gmax (eval/Evaluator.java:241-242): the trainer created next uses it
         handle = RlHipNative.create(nTrees, nTreeLeaves, nThreshold, minLeafSupport, nRoundToStopEarly, learningRate, metric, scorer.getK(),
                 rankerId(), device, FeatureHistogram.samplingRate, seed++, javaOrder ? 16 : 0);
         impacts = new double[features.length];
         try {
             final Map<String, Integer> qids = new HashMap<>();
             upload(samples, false, qids);
-            if (validationSamples != null) upload(validationSamples, true, qids);
+            forwardJudgments(samples, false);
+            if (validationSamples != null) { upload(validationSamples, true, qids); forwardJudgments(validationSamples, true); }
             RlHipNative.init(handle);
         } catch (final RuntimeException e) {      // never leak the device memory behind a failed init
             RlHipNative.destroy(handle);
@@ -116,7 +154,7 @@ public class LambdaMART extends Ranker {
         logger.info(() -> "Training starts...");
         if (validationSamples != null) printLogLn(new int[] { 7, 9, 9 }, new String[] { "#iter", scorer.name() + "-T", scorer.name() + "-V" });
         else printLogLn(new int[] { 7, 9 }, new String[] { "#iter", scorer.name() + "-T" });
-        final int cap = Math.max(3, 2 * nTreeLeaves - 1);          // the root always splits once (RegressionTree.java:62-67): -leaf 1 still yields 3 nodes
+        final int cap = RlHipNative.treeCapacity(handle);          // 2 * leaves - 1, at least 3 (the root always splits once, RegressionTree.java:62-67); -leaf -1: 2 * (N / mls) - 1
         final int[] feature = new int[cap], left = new int[cap], right = new int[cap];
         final float[] threshold = new float[cap], output = new float[cap], metrics = new float[2];
         try {

@@ -10,6 +10,10 @@ final class RlHipNative {
     static native long create(int nTrees, int nLeaves, int nThreshold, int minLeafSupport, int stopEarly, float lr, int metric, int k,
             int ranker, int device, float featureSamplingRate, long seed, int flags);
     static native void destroy(long h);
+    /** ERRScorer.MAX (-gmax): process-wide, before create (rlhip.h rl_set_err_max) */
+    static native int setErrMax(double maxGain);
+    /** nodes of the largest possible tree, after init: the array length boostRound needs (rlhip.h rl_tree_capacity) */
+    static native int treeCapacity(long h);
     static native int setData(long h, boolean validation, FloatBuffer X, long nDocs, int nFeatures, float[] labels, int[] qoff,
             int[] featureIds, int[] qkey);
     /** a block of rows after setData(.., X = null, ..): X holds nDocs * nFeatures floats from position 0 (rlhip.h rl_set_rows) */

@@ -37,6 +37,14 @@ JNIEXPORT jlong JNICALL Java_ciir_umass_edu_learning_tree_RlHipNative_create(JNI
     return (jlong)(intptr_t)t;
 }
 
+/* ERRScorer.MAX (-gmax): a process-wide static on both sides; call before create() */
+JNIEXPORT jint JNICALL Java_ciir_umass_edu_learning_tree_RlHipNative_setErrMax(JNIEnv *env, jclass c, jdouble maxGain)
+{ CHECK(rl_set_err_max(maxGain)); return 0; }
+
+/* nodes of the largest possible tree (after init): the array length boostRound needs, also for -leaf -1 */
+JNIEXPORT jint JNICALL Java_ciir_umass_edu_learning_tree_RlHipNative_treeCapacity(JNIEnv *env, jclass c, jlong h)
+{ int32_t n = 0; CHECK(rl_tree_capacity((rl_trainer *)(intptr_t)h, &n)); return n; }
+
 JNIEXPORT void JNICALL Java_ciir_umass_edu_learning_tree_RlHipNative_destroy(JNIEnv *env, jclass c, jlong h)
 { rl_destroy((rl_trainer *)(intptr_t)h); }
 

@@ -35,10 +35,10 @@ class RlTree(C.Structure):
                 ("deviance", C.POINTER(C.c_double)), ("count", C.POINTER(C.c_int32))]
 
 
-RL_FLAG_FAST_LEAF, RL_FLAG_TIMING, RL_FLAG_SERIAL_CHAIN, RL_FLAG_TIMING_NODES, RL_FLAG_JAVA_ORDER = 1, 2, 4, 8, 16
+RL_FLAG_TIMING, RL_FLAG_SERIAL_CHAIN, RL_FLAG_TIMING_NODES, RL_FLAG_JAVA_ORDER = 2, 4, 8, 16
 ARR = dict(LAMBDA=1, WEIGHT=2, SCORE=3, VALID_SCORE=4, NBINS=5, THRESHOLDS=6, BINS=7, ROOT_COUNT=8, ROOT_SUM=9,
            QUANT=10, ROOT_SUM_FIXED=11, NDCG_PER_QUERY=12, CHAIN_STATS=13, CHAIN_MISS=14, GROW_STATS=15, PHASE_CLOCKS=16,
-           ROOT_SUM_JAVA=17, GROW_DOCS=18, SPARSE_INFO=19)
+           ROOT_SUM_JAVA=17, GROW_DOCS=18, SPARSE_INFO=19, STEP_LOG=20)
 KERNEL = dict(HIST_ROOT=0, HIST_NODE=1, LAMBDA=2)
 
 # every symbol include/rlhip.h declares (tests/test_abi.py checks the .so exports all of them)
@@ -49,11 +49,12 @@ ABI_SYMBOLS = [
     "rl_model_to_text", "rl_model_from_text", "rl_model_destroy", "rl_model_num_trees", "rl_model_features",
     "rl_model_predict", "rl_model_predict_device", "rl_dist_unique_id", "rl_dist_init", "rl_dist_init_callback", "rl_dist_stats", "rl_bin_stride", "rl_quant_exponent", "rl_get_array", "rl_debug_exp", "rl_debug_float_chain",
     "rl_letor_parse", "rl_letor_info", "rl_letor_arrays", "rl_letor_rows", "rl_letor_destroy",
-    "rl_get_timing", "rl_reset_timing", "rl_set_timing_flags", "rl_debug_membench", "rl_set_err_max",
+    "rl_get_timing", "rl_reset_timing", "rl_set_timing_flags", "rl_debug_membench", "rl_set_err_max", "rl_tree_capacity",
 ]
 
 HOST_ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32)
 HOST_ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+HOST_ALLTOALLV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64))
 DT_NUMPY = {0: np.int64, 1: np.uint64, 2: np.int32, 3: np.uint32, 4: np.float64}
 
 _lib = None
@@ -87,6 +88,7 @@ def lib():
     L.rl_sync.argtypes = [vp]
     L.rl_finish.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.rl_num_trees.argtypes = [vp, C.POINTER(i32)]
+    L.rl_tree_capacity.argtypes = [vp, C.POINTER(i32)]
     L.rl_get_tree.argtypes = [vp, i32, C.POINTER(RlTree)]
     L.rl_get_round_metrics.argtypes = [vp, i32, f32p, f32p]
     L.rl_best_validation.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_double)]
@@ -102,7 +104,7 @@ def lib():
     L.rl_dist_unique_id.argtypes = [vp]
     L.rl_dist_init.argtypes = [vp, vp, i32, i32]
     L.rl_dist_stats.argtypes = [vp, vp]
-    L.rl_dist_init_callback.argtypes = [vp, i32, i32, HOST_ALLREDUCE, HOST_ALLGATHER, vp]
+    L.rl_dist_init_callback.argtypes = [vp, i32, i32, HOST_ALLREDUCE, HOST_ALLGATHER, HOST_ALLTOALLV, vp]
     L.rl_bin_stride.argtypes = [vp, C.POINTER(i32)]
     L.rl_quant_exponent.argtypes = [vp, C.POINTER(i32)]
     L.rl_get_array.argtypes = [vp, i32, vp, i64]
@@ -291,13 +293,15 @@ class Trainer:
         check(lib().rl_dist_init(self.h, uid, rank, n_ranks))
 
     def dist_stats(self):
-        """[all-reduce calls, all-reduce bytes, all-gather calls, all-gather bytes received] of this rank so far"""
-        out = np.zeros(4, np.int64)
+        """[all-reduce calls, all-reduce bytes, all-gather calls, all-gather bytes received, all-to-all calls, all-to-all bytes received from
+        other ranks] of this rank so far"""
+        out = np.zeros(6, np.int64)
         check(lib().rl_dist_stats(self.h, out.ctypes.data))
         return out
 
-    def dist_init_callback(self, rank, n_ranks, allreduce, allgather):
-        """host transport: allreduce(np_array, op) reduces in place, allgather(np_uint8_in) -> np_uint8 [n_ranks*len]"""
+    def dist_init_callback(self, rank, n_ranks, allreduce, allgather, alltoallv=None):
+        """host transport: allreduce(np_array, op) reduces in place, allgather(np_uint8_in) -> np_uint8 [n_ranks*len],
+        alltoallv(list of n_ranks np_uint8 arrays to send) -> list of n_ranks np_uint8 arrays received (None: emulated with all-gathers)"""
         def _ar(user, ptr, count, dtype, op):
             try:
                 arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), (count * np.dtype(DT_NUMPY[dtype]).itemsize,)).view(DT_NUMPY[dtype])
@@ -316,11 +320,30 @@ class Trainer:
             except Exception as e:          # noqa: BLE001
                 print("host all-gather callback failed:", e)
                 return 1
-        self._cb = (HOST_ALLREDUCE(_ar), HOST_ALLGATHER(_ag))      # keep alive
-        check(lib().rl_dist_init_callback(self.h, rank, n_ranks, self._cb[0], self._cb[1], None))
+
+        def _aa(user, psend, scount, sdispl, precv, rcount, rdispl):
+            try:
+                sb = max([sdispl[p] + scount[p] for p in range(n_ranks)] + [1])
+                rb = max([rdispl[p] + rcount[p] for p in range(n_ranks)] + [1])
+                snd = np.ctypeslib.as_array(C.cast(psend, C.POINTER(C.c_uint8)), (sb,))
+                rcv = np.ctypeslib.as_array(C.cast(precv, C.POINTER(C.c_uint8)), (rb,))
+                got = alltoallv([snd[sdispl[p]:sdispl[p] + scount[p]] for p in range(n_ranks)], [int(rcount[p]) for p in range(n_ranks)])
+                for p in range(n_ranks):
+                    if len(got[p]) != rcount[p]:
+                        raise ValueError("rank %d sent %d bytes, %d expected" % (p, len(got[p]), rcount[p]))
+                    rcv[rdispl[p]:rdispl[p] + rcount[p]] = got[p]
+                return 0
+            except Exception as e:          # noqa: BLE001
+                print("host all-to-all callback failed:", e)
+                return 1
+        self._cb = (HOST_ALLREDUCE(_ar), HOST_ALLGATHER(_ag), HOST_ALLTOALLV(_aa) if alltoallv is not None else None)      # keep alive
+        check(lib().rl_dist_init_callback(self.h, rank, n_ranks, self._cb[0], self._cb[1], self._cb[2], None))
 
     def init(self):
         check(lib().rl_init(self.h))
+        cap = C.c_int32(0)
+        check(lib().rl_tree_capacity(self.h, C.byref(cap)))      # -leaf -1: 2 * floor(N_global / mls) - 1
+        self.cap = cap.value
 
     def boost_round(self, want_tree=True):
         t = FlatTree(self.cap) if want_tree else None
@@ -396,7 +419,7 @@ class Trainer:
             "THRESHOLDS": ((self.F, TS), np.float32), "BINS": ((self.F, self.N), np.uint16),
             "ROOT_COUNT": ((self.F, TS), np.int32), "ROOT_SUM": ((self.F, TS), np.float64), "ROOT_SUM_JAVA": ((self.F, TS), np.float64),
             "QUANT": ((self.N,), np.int64), "ROOT_SUM_FIXED": ((self.F, TS, 2), np.int64),
-            "NDCG_PER_QUERY": ((self.Q,), np.float64), "CHAIN_STATS": ((6,), np.int32), "GROW_STATS": ((4,), np.int32), "GROW_DOCS": ((4,), np.int64), "SPARSE_INFO": ((4,), np.int64), "PHASE_CLOCKS": ((64, 16), np.int64), "CHAIN_MISS": ((2, 2 * max(self.p.n_leaves, 1)), np.int32),
+            "NDCG_PER_QUERY": ((self.Q,), np.float64), "CHAIN_STATS": ((6,), np.int32), "GROW_STATS": ((4,), np.int32), "GROW_DOCS": ((4,), np.int64), "SPARSE_INFO": ((4,), np.int64), "PHASE_CLOCKS": ((64, 16), np.int64), "STEP_LOG": ((8 + 8 * 8192,), np.int32), "CHAIN_MISS": ((2, self.cap + 1), np.int32),
         }
         shape, dt = shapes[name]
         out = np.zeros(shape, dt)

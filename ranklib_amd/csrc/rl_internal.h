@@ -60,7 +60,8 @@ struct NodeRec {
     int32_t pl, pr;          // prepared children, -1 while unprepared
     int32_t fid;             // id in the exported tree (creation order of the COMMITTED splits), -1 = not part of the tree
     int32_t prepared;
-    int32_t best_cl, pad_;   // cumulative histogram entry at the best split: count ...
+    int32_t best_cl, tie;    // cumulative histogram entry at the best split: count ...; tie: other candidates reach best_S exactly --
+                             // 1 = only inside the winning feature (an empty-bin plateau), 2 = in several features (see rl_tie.inc)
     unsigned long long ph;   // path hash of the node: keys the seeded feature draw of its split attempt (rl_params.seed)
     long long best_hi; unsigned long long best_lo;   // ... and exact fixed-point sum (= the left child's totals)
 };
@@ -169,6 +170,7 @@ struct Ctx {
     double *jtot;            // [kSpec][2]  sumResponse, sqSumResponse of the same nodes (FeatureHistogram.java:133-137,182-186)
     double *jcum;            // [NC][F][TS] cumulative Java-order sums of every live node
     const uint16_t *jmap, *jinv; const uint32_t *jone;      // k_jhist2: bin -> owning (wavefront, lane), its inverse, single-bin wavefronts (null: k_jhist)
+    int32_t *steplog;        // debug (RLHIP_STEPLOG=1, RL_ARR_STEP_LOG): [0] = entries written, then 8-int entries: growth-step slots and committed tied splits
     long long *clk;          // [64][16] wall-clock stamps (10 ns units) of the finish / select phases of the last 64 growth steps; only
                              // written by builds with -DRL_PHASE_CLOCKS (tools/phase_clocks.py), RL_ARR_PHASE_CLOCKS reads it
 };

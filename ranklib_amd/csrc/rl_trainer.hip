@@ -117,7 +117,9 @@ struct rl_trainer {
     std::vector<int32_t> all_N, all_Q;        // local sizes of every rank
     int64_t Nglobal = 0; int32_t Qglobal = 0, Qmax = 0;
     ChainBufs gchain;                          // float chains over the all-gathered leaf values
-    double *d_gx = nullptr; int32_t *d_gls = nullptr; int32_t lsstride = 0; float *d_gres = nullptr;
+    double *d_gx = nullptr, *d_send = nullptr; int32_t *d_gls = nullptr; int32_t lsstride = 0; float *d_gres = nullptr;     // leaf-owner exchange: receive / send buffers
+    int32_t *d_own = nullptr; long long *d_xtab = nullptr;     // owner of every leaf; pack / assemble offsets (rl_dist.inc LeafExchange)
+    std::vector<int32_t> h_gls, h_own; std::vector<long long> h_xtab;
     double *d_qsend = nullptr, *d_qgath = nullptr, *d_qcat = nullptr; int32_t *d_allQ = nullptr;
     // the same for the validation set (sharded by query like the training set)
     int32_t vQglobal = 0, vQmax = 0; double *d_vqsend = nullptr, *d_vqgath = nullptr, *d_vqcat = nullptr; int32_t *d_vallQ = nullptr;
@@ -592,23 +594,62 @@ static int enqueue_round(rl_trainer *t)
         hipLaunchKernelGGL(k_leaf_chain, dim3(c.L), dim3(64), 0, s, c);
     } else if (t->dist) {
         // multi-GPU: gather lambda / weight in leaf order from every rank and evaluate the chains over the whole leaf
+        // multi-GPU, the leaf-owner exchange (rl_dist.inc): lambda / weight of a leaf's documents go to the leaf's owner rank only
         ChainSource src{nullptr, nullptr, c.lw, c.idx[0], c.idx[1], t->d_seg_buf};
         const ChainBufs &lb = t->leaf_chain;
-        hipLaunchKernelGGL(k_chain_prefix, dim3((unsigned)((lb.cap_tiles + 3) / 4)), dim3(kThreads), 0, s, lb, src);
-        int rcd = t->dist->allgather(lb.xs, t->d_gx, (size_t)lb.A * lb.cap_n * sizeof(double), s);
+        const int R = t->n_ranks, me = t->dist->rank, nseg = std::max(c.L, 2), MS = t->gchain.maxseg;      // -leaf 1 still has two leaves (the root always splits)
+        hipLaunchKernelGGL(k_chain_prefix, dim3((unsigned)((lb.cap_tiles + 3) / 4)), dim3(kThreads), 0, s, lb, src);      // local values in leaf order -> lb.xs
+        int rcd = t->dist->allgather(c.leaf_start, t->d_gls, (size_t)t->lsstride * sizeof(int32_t), s);
         if (rcd) return rcd;
-        rcd = t->dist->allgather(c.leaf_start, t->d_gls, (size_t)t->lsstride * sizeof(int32_t), s);
+        // the send / receive counts of the exchange have to be known to the host: one small copy per round (sharded runs are host-paced anyway)
+        std::vector<int32_t> &gls = t->h_gls;
+        gls.resize((size_t)R * t->lsstride);
+        RL_HIP(hipMemcpyAsync(gls.data(), t->d_gls, gls.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        RL_HIP(hipStreamSynchronize(s));
+        auto len_of = [&](int r, int l) { return (long long)gls[(size_t)r * t->lsstride + l + 1] - gls[(size_t)r * t->lsstride + l]; };
+        std::vector<int32_t> &own = t->h_own; own.assign((size_t)MS, 0);
+        {   // owners: largest leaf first onto the least loaded rank (every rank computes the same map from the same table)
+            std::vector<long long> glen((size_t)nseg, 0), load((size_t)R, 0);
+            std::vector<int32_t> order((size_t)nseg);
+            for (int l = 0; l < nseg; l++) { order[l] = l; for (int r = 0; r < R; r++) glen[l] += len_of(r, l); }
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return glen[a] > glen[b]; });
+            for (int l : order) {
+                if (glen[l] == 0) { own[l] = l % R; continue; }
+                int o = 0;
+                for (int r = 1; r < R; r++) if (load[r] < load[o]) o = r;
+                own[l] = o; load[o] += glen[l];
+            }
+        }
+        std::vector<long long> &tab = t->h_xtab; tab.assign((size_t)MS * (R + 1), 0);       // pack_off [MS] | asm_off [R][MS]
+        std::vector<int64_t> scount(R), sdispl(R), rcount(R), rdispl(R);
+        long long cur = 0;
+        for (int d = 0; d < R; d++) {
+            sdispl[d] = cur * 8;
+            for (int l = 0; l < nseg; l++) if (own[l] == d) { tab[l] = cur; cur += 2 * len_of(me, l); }
+            scount[d] = cur * 8 - sdispl[d];
+        }
+        cur = 0;
+        for (int r = 0; r < R; r++) {
+            rdispl[r] = cur * 8;
+            for (int l = 0; l < nseg; l++) if (own[l] == me) { tab[(size_t)MS * (1 + r) + l] = cur; cur += 2 * len_of(r, l); }
+            rcount[r] = cur * 8 - rdispl[r];
+        }
+        RL_HIP(hipMemcpyAsync(t->d_own, own.data(), (size_t)MS * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        RL_HIP(hipMemcpyAsync(t->d_xtab, tab.data(), tab.size() * sizeof(long long), hipMemcpyHostToDevice, s));
+        const LeafExchange lx{t->d_own, t->d_xtab, t->d_xtab + MS};
+        hipLaunchKernelGGL(k_chain_pack, dim3(nseg, 2), dim3(kThreads), 0, s, (const double *)lb.xs, lb.cap_n, (const int32_t *)c.leaf_start, nseg, lx, t->d_send);
+        rcd = t->dist->alltoallv(t->d_send, scount.data(), sdispl.data(), t->d_gx, rcount.data(), rdispl.data(), s);
         if (rcd) return rcd;
-        hipLaunchKernelGGL(k_plan_global, dim3(1), dim3(64), 0, s, (const int32_t *)t->d_gls, t->n_ranks, t->lsstride, c.L, t->gchain, t->dist->rank);
-        hipLaunchKernelGGL(k_chain_assemble, dim3(c.L, 2), dim3(kThreads), 0, s, (const double *)t->d_gx, (const int32_t *)t->d_gls, t->n_ranks, 2,
-                           (int)lb.cap_n, t->lsstride, c.L, t->gchain, t->dist->rank);
+        hipLaunchKernelGGL(k_plan_global, dim3(1), dim3(64), 0, s, (const int32_t *)t->d_gls, R, t->lsstride, nseg, t->gchain, (const int32_t *)t->d_own, me);
+        hipLaunchKernelGGL(k_chain_assemble, dim3(nseg, 2), dim3(kThreads), 0, s, (const double *)t->d_gx, (const int32_t *)t->d_gls, R, t->lsstride, nseg, lx,
+                           t->gchain, me);
         ChainSource gsrc{t->gchain.xs, t->gchain.xs + t->gchain.cap_n, nullptr, nullptr, nullptr, nullptr};
         enqueue_chain(t, t->gchain, gsrc);
-        if (t->n_ranks > 1) {       // every rank evaluated its own leaves: exchange the 2 L float sums
-            rcd = t->dist->allgather(t->gchain.result, t->d_gres, (size_t)2 * t->gchain.maxseg * sizeof(float), s);
+        if (R > 1) {       // every rank evaluated its own leaves: exchange the 2 L float sums
+            rcd = t->dist->allgather(t->gchain.result, t->d_gres, (size_t)2 * MS * sizeof(float), s);
             if (rcd) return rcd;
-            hipLaunchKernelGGL(k_chain_pick, dim3((2 * c.L + kThreads - 1) / kThreads), dim3(kThreads), 0, s, (const float *)t->d_gres, t->n_ranks, 2,
-                               t->gchain.maxseg, c.L, t->gchain.result);
+            hipLaunchKernelGGL(k_chain_pick, dim3((2 * nseg + kThreads - 1) / kThreads), dim3(kThreads), 0, s, (const float *)t->d_gres, R, 2,
+                               MS, nseg, (const int32_t *)t->d_own, t->gchain.result);
         }
         hipLaunchKernelGGL(k_leaf_output, dim3((c.L + kThreads - 1) / kThreads), dim3(kThreads), 0, s, c, t->gchain);
     } else {   // K7: the two Java float running sums of every leaf, exactly, in parallel (rl_chain.inc)
@@ -760,7 +801,6 @@ int rl_set_external_judgments(rl_trainer *t, int32_t validation, const double *i
     if (check_trainer(t)) return RL_ERR_INVALID;
     if (t->inited) return fail(RL_ERR_STATE, "rl_set_external_judgments must be called before rl_init");
     if (validation ? !t->has_valid : !t->has_train) return fail(RL_ERR_STATE, "set the data first");
-    if (t->dist) return fail(RL_ERR_UNSUPPORTED, "external relevance judgments with multi-GPU training");
     DataSet &d = validation ? t->va : t->tr;
     d.ext_ideal.clear(); d.ext_rd.clear();
     if (ideal_dcg) d.ext_ideal.assign(ideal_dcg, ideal_dcg + d.Q);
@@ -793,7 +833,7 @@ int rl_create(const rl_params *p, rl_trainer **out)
     if (p->min_leaf_support < 1) return fail(RL_ERR_INVALID, "min_leaf_support must be >= 1");
     if (p->n_threshold != -1 && (p->n_threshold < 1 || p->n_threshold + 1 > kMaxBins))
         return fail(RL_ERR_UNSUPPORTED, "n_threshold must be -1 or in [1," + std::to_string(kMaxBins - 1) + "]");
-    if (p->flags & RL_FLAG_FAST_LEAF) return fail(RL_ERR_UNSUPPORTED, "RL_FLAG_FAST_LEAF is not built yet");
+    if (p->flags & ~(RL_FLAG_TIMING | RL_FLAG_TIMING_NODES | RL_FLAG_SERIAL_CHAIN | RL_FLAG_JAVA_ORDER)) return fail(RL_ERR_INVALID, "unknown bit in rl_params.flags");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(RL_ERR_NO_DEVICE, "no HIP device visible: librlhip has no CPU fallback");
@@ -929,11 +969,17 @@ int rl_init(rl_trainer *t)
     // documents: a budget of floor(N / mls) leaves never binds before the Java's own loop ends.
     int L_eff = t->p.n_leaves;
     if (L_eff == -1) {
-        if (t->dist) return fail(RL_ERR_UNSUPPORTED, "-leaf -1 with multi-GPU training");
-        L_eff = std::max(1, N / std::max(1, t->p.min_leaf_support));
-        const double need = (4.0 * L_eff + 2.0) * F * 264.0 * 28.0;
-        if (need > 96e9) return fail(RL_ERR_UNSUPPORTED, "-leaf -1: up to " + std::to_string(L_eff) + " leaves would need " + std::to_string((long long)(need / 1e9)) +
-                                                         " GB of node histograms; raise -mls or set -leaf");
+        long long Nall = N;          // sharded: the budget comes from the GLOBAL document count (every rank grows the same tree)
+        if (t->dist) {
+            long long *d_n = nullptr;
+            RL_HIP(t->pool.alloc(&d_n, (size_t)1));
+            RL_HIP(hipMemcpy(d_n, &Nall, sizeof(Nall), hipMemcpyHostToDevice));
+            int rcd = t->dist->allreduce(d_n, 1, DT_I64, OP_SUM, s); if (rcd) return rcd;
+            RL_HIP(hipStreamSynchronize(s));
+            RL_HIP(hipMemcpy(&Nall, d_n, sizeof(Nall), hipMemcpyDeviceToHost));
+            t->pool.release(d_n);
+        }
+        L_eff = (int)std::max<long long>(1, std::min<long long>(Nall / std::max(1, t->p.min_leaf_support), 1 << 28));
     }
     t->L_eff = L_eff;
     c.N = N; c.Npad = Npad; c.Q = t->tr.Q; c.F = F; c.L = L_eff;
@@ -1023,6 +1069,13 @@ int rl_init(rl_trainer *t)
         c.live = d_live; c.n_live = (int32_t)live.size();
     }
     if ((size_t)TS * 12 > (size_t)kHistLdsBytes) return fail(RL_ERR_UNSUPPORTED, "too many threshold candidates for the LDS histogram");
+    if (t->p.n_leaves == -1) {      // -leaf -1: the node histograms are sized for floor(N / mls) leaves -- say so before an allocation fails
+        const double need = (double)c.NC * F * TS * ((t->p.flags & RL_FLAG_JAVA_ORDER) ? 28.0 : 20.0);
+        size_t mem_free = 0, mem_total = 0;
+        RL_HIP(hipMemGetInfo(&mem_free, &mem_total));
+        if (need > 0.8 * (double)mem_free) return fail(RL_ERR_UNSUPPORTED, "-leaf -1: up to " + std::to_string(L_eff) + " leaves would need " + std::to_string((long long)(need / 1e9)) +
+                                                                          " GB of node histograms; raise -mls or set -leaf");
+    }
     // features of a 16-feature group handled by one histogram block: all 16 when the LDS budget allows
     c.FG = kHistFG;
     c.numFG = (F + kHistFG - 1) / kHistFG;
@@ -1285,6 +1338,8 @@ int rl_init(rl_trainer *t)
     RL_HIP(t->pool.alloc(&c.tile_desc, (size_t)c.nTiles)); RL_HIP(hipMemset(c.tile_desc, 0, (size_t)c.nTiles * 8));
     RL_HIP(t->pool.alloc(&c.grow_stats, (size_t)4)); RL_HIP(hipMemset(c.grow_stats, 0, 16));
     RL_HIP(t->pool.alloc(&c.grow_docs, (size_t)4)); RL_HIP(hipMemset(c.grow_docs, 0, 32));
+    c.steplog = nullptr;
+    if (getenv("RLHIP_STEPLOG")) { RL_HIP(t->pool.alloc(&c.steplog, (size_t)8 + 8 * kStepLogCap)); RL_HIP(hipMemset(c.steplog, 0, ((size_t)8 + 8 * kStepLogCap) * sizeof(int32_t))); }
     RL_HIP(t->pool.alloc(&c.clk, (size_t)64 * 16)); RL_HIP(hipMemset(c.clk, 0, 64 * 16 * sizeof(long long)));
     RL_HIP(t->pool.alloc(&c.leaf_node, (size_t)c.MAXN + 1)); RL_HIP(t->pool.alloc(&c.leaf_start, (size_t)c.MAXN + 2));
     RL_HIP(t->pool.alloc(&c.round_metric, (size_t)2 * t->p.n_trees));
@@ -1336,7 +1391,9 @@ int rl_init(rl_trainer *t)
             rc = alloc_chain(t, t->gchain, c.MAXN + 1, 2, t->Nglobal, true);
             if (rc) return rc;
             t->lsstride = c.MAXN + 2;
-            RL_HIP(t->pool.alloc(&t->d_gx, (size_t)t->n_ranks * 2 * t->leaf_chain.cap_n));
+            RL_HIP(t->pool.alloc(&t->d_gx, (size_t)2 * t->Nglobal + 2));              // at worst one rank owns every leaf
+            RL_HIP(t->pool.alloc(&t->d_send, (size_t)2 * N + 2));
+            RL_HIP(t->pool.alloc(&t->d_own, (size_t)c.MAXN + 1)); RL_HIP(t->pool.alloc(&t->d_xtab, (size_t)(c.MAXN + 1) * (t->n_ranks + 1)));
             RL_HIP(t->pool.alloc(&t->d_gls, (size_t)t->n_ranks * t->lsstride));
             RL_HIP(t->pool.alloc(&t->d_gres, (size_t)t->n_ranks * 2 * (c.MAXN + 1) + 8));
             RL_HIP(t->pool.alloc(&t->d_qsend, (size_t)t->Qmax)); RL_HIP(t->pool.alloc(&t->d_qgath, (size_t)t->n_ranks * t->Qmax));
@@ -1471,6 +1528,14 @@ int rl_num_trees(const rl_trainer *t, int32_t *n)
     return RL_OK;
 }
 
+int rl_tree_capacity(const rl_trainer *t, int32_t *cap)
+{
+    if (check_trainer(t)) return RL_ERR_INVALID;
+    if (!t->inited) return fail(RL_ERR_STATE, "rl_init has not been called");
+    if (cap) *cap = t->ctx.MAXN;
+    return RL_OK;
+}
+
 int rl_get_tree(const rl_trainer *t, int32_t i, rl_tree *out)
 {
     if (check_trainer(t)) return RL_ERR_INVALID;
@@ -1587,19 +1652,22 @@ int rl_dist_stats(const rl_trainer *t, int64_t *out)
 {
     if (check_trainer(t)) return RL_ERR_INVALID;
     if (!out) return fail(RL_ERR_INVALID, "null argument");
-    out[0] = out[1] = out[2] = out[3] = 0;
-    if (t->dist) { out[0] = t->dist->n_allreduce; out[1] = t->dist->b_allreduce; out[2] = t->dist->n_allgather; out[3] = t->dist->b_allgather; }
+    out[0] = out[1] = out[2] = out[3] = out[4] = out[5] = 0;
+    if (t->dist) {
+        out[0] = t->dist->n_allreduce; out[1] = t->dist->b_allreduce; out[2] = t->dist->n_allgather; out[3] = t->dist->b_allgather;
+        out[4] = t->dist->n_alltoall; out[5] = t->dist->b_alltoall;
+    }
     return RL_OK;
 }
 
 int rl_dist_init_callback(rl_trainer *t, int32_t rank, int32_t n_ranks, rl_host_allreduce_fn allreduce, rl_host_allgather_fn allgather,
-                          void *user)
+                          rl_host_alltoallv_fn alltoallv, void *user)
 {
     int rc = dist_precheck(t, rank, n_ranks);
     if (rc) return rc;
     if (!allreduce || !allgather) return fail(RL_ERR_INVALID, "null callback");
     std::unique_ptr<CallbackBackend> b(new CallbackBackend());
-    b->ar = allreduce; b->ag = allgather; b->user = user; b->rank = rank; b->n = n_ranks;
+    b->ar = allreduce; b->ag = allgather; b->aa = alltoallv; b->user = user; b->rank = rank; b->n = n_ranks;
     t->rank = rank; t->n_ranks = n_ranks;
     t->dist = std::move(b);
     return RL_OK;
@@ -1652,6 +1720,12 @@ int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes)
         const int64_t v[4] = {c.sp_on ? c.sp_ngroups : 0, t->sp_entries, c.sp_on ? c.numFG - c.sp_ngroups : c.numFG, t->sp_cols};
         if (cap_bytes < (int64_t)sizeof(v)) return fail(RL_ERR_INVALID, "output buffer too small");
         memcpy(out, v, sizeof(v));
+        return RL_OK;
+    }
+    case RL_ARR_STEP_LOG: {
+        bytes = ((size_t)8 + 8 * kStepLogCap) * sizeof(int32_t);
+        if ((int64_t)bytes > cap_bytes) return fail(RL_ERR_INVALID, "output buffer too small");
+        if (c.steplog) RL_HIP(hipMemcpy(out, c.steplog, bytes, hipMemcpyDeviceToHost)); else memset(out, 0, bytes);
         return RL_OK;
     }
     case RL_ARR_PHASE_CLOCKS: src = c.clk; bytes = 64 * 16 * sizeof(long long); break;

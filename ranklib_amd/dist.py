@@ -66,6 +66,55 @@ class TorchHostTransport:
         return np.concatenate([o.numpy() for o in outs])
 
 
+    def alltoallv(self, send, recv_bytes):
+        """send[p]: uint8 array for rank p; recv_bytes[p]: bytes rank p sends here -> list of received uint8 arrays (own part included).
+        Point-to-point over the group (gloo has no all_to_all for CPU tensors): posted in one batch, so there is no ordering to deadlock on."""
+        torch, dist = self.torch, self.dist
+        me = dist.get_rank(self.group)
+        out = [np.empty(int(recv_bytes[p]), np.uint8) for p in range(self.n)]
+        out[me][:] = send[me]
+        keep, ops = [], []
+        for p in range(self.n):
+            if p == me:
+                continue
+            if len(send[p]):
+                ts = torch.from_numpy(np.ascontiguousarray(send[p])); keep.append(ts)
+                ops.append(dist.P2POp(dist.isend, ts, dist.get_global_rank(self.group, p) if self.group is not None else p, group=self.group))
+            if recv_bytes[p]:
+                tr = torch.from_numpy(out[p])
+                ops.append(dist.P2POp(dist.irecv, tr, dist.get_global_rank(self.group, p) if self.group is not None else p, group=self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return out
+
+
+# ---- the leaf-owner exchange, restated on the host (what rl_trainer.hip enqueue_round + rl_dist.inc do per round; CPU tests) ----
+def leaf_owners(glen, n_ranks):
+    """owner rank of every leaf: largest leaf (documents over all ranks) first onto the least loaded rank, lowest rank on a tie;
+    empty leaf slots go to l % n_ranks.  Every rank computes this from the same gathered leaf tables."""
+    glen = [int(v) for v in glen]
+    own, load = [0] * len(glen), [0] * n_ranks
+    for l in sorted(range(len(glen)), key=lambda l: -glen[l]):          # stable: ties keep ascending leaf order
+        if glen[l] == 0:
+            own[l] = l % n_ranks
+            continue
+        o = min(range(n_ranks), key=lambda r: (load[r], r))
+        own[l] = o
+        load[o] += glen[l]
+    return own
+
+
+def leaf_exchange_plan(lens, me):
+    """lens[r][l] = documents of leaf l on rank r.  -> (own, send blocks per destination, receive blocks per source) for rank `me`:
+    a block is (leaf, documents); rank r's block of leaf l holds its lambda segment then its weight segment (2 * 8 * documents bytes)."""
+    R, L = len(lens), len(lens[0])
+    own = leaf_owners([sum(lens[r][l] for r in range(R)) for l in range(L)], R)
+    send = [[(l, lens[me][l]) for l in range(L) if own[l] == d] for d in range(R)]
+    recv = [[(l, lens[r][l]) for l in range(L) if own[l] == me] for r in range(R)]
+    return own, send, recv
+
+
 # ---- exact 128-bit sums over int64 limbs (what the library does on the device; restated for the CPU tests) ----
 LIMB_SHIFT = 44
 

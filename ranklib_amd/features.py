@@ -121,7 +121,8 @@ class FeatureManager:
     def _cache_save(inputFile, arrays):
         try:
             tmp = FeatureManager._cache_path(inputFile) + ".tmp.npz"
-            np.savez(tmp, **arrays)
+            st = os.stat(inputFile)
+            np.savez(tmp, src_size=np.int64(st.st_size), src_mtime_ns=np.int64(st.st_mtime_ns), **arrays)
             os.replace(tmp, FeatureManager._cache_path(inputFile))
         except OSError as ex:          # read-only directory: the cache is an optimisation
             logger.info("no LETOR cache written: %s", ex)
@@ -130,9 +131,12 @@ class FeatureManager:
     def _cache_load(inputFile):
         path = FeatureManager._cache_path(inputFile)
         try:
-            if os.path.getmtime(path) < os.path.getmtime(inputFile):
-                return None
+            st = os.stat(inputFile)
             with np.load(path) as z:
+                # the cache names the text it was made from (size and mtime in ns): a file rewritten within the timestamp granularity, or
+                # restored with an older mtime (cp -p, rsync -t, git checkout), never yields stale rows
+                if int(z["src_size"]) != st.st_size or int(z["src_mtime_ns"]) != st.st_mtime_ns:
+                    return None
                 return {k: z[k] for k in ("X", "labels", "last_fid", "max_fid", "qids", "descs")}
         except (OSError, KeyError, ValueError):
             return None

@@ -19,15 +19,22 @@ def main():
 
     out_path, n_docs, n_feat, kind, seed, leaves, rounds = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
     ranker, metric, k = (sys.argv[8], sys.argv[9], int(sys.argv[10])) if len(sys.argv) > 10 else ("LAMBDAMART", "NDCG", 10)
-    opts = sys.argv[11].split(",") if len(sys.argv) > 11 else []       # "valid": sharded validation set + early stopping; "rccl": RCCL transport
+    # "valid": sharded validation set + early stopping; "rccl": RCCL transport; "noa2a": a transport without an all-to-all (emulated with all-gathers);
+    # "leafm1": -leaf -1 with min leaf support 40; "qrel": external judgments (a third of the lists get an ideal DCG of their own times 1.5)
+    opts = sys.argv[11].split(",") if len(sys.argv) > 11 else []
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     X, lab, qoff = synth.make_dataset(n_docs, n_feat, kind, seed_offset=seed)
     Xs, ls, qs = D.shard(X, lab, qoff, rank, world)
     tr = D.TorchHostTransport()
     estop = 1 if "valid" in opts else 100
-    g = N.Trainer(n_trees=rounds, n_leaves=leaves, ranker=ranker, metric=metric, metric_k=k, early_stop_rounds=estop)
+    g = N.Trainer(n_trees=rounds, n_leaves=-1 if "leafm1" in opts else leaves, ranker=ranker, metric=metric, metric_k=k, early_stop_rounds=estop,
+                  min_leaf_support=40 if "leafm1" in opts else 1)
     g.set_train(Xs, ls, qs)
+    if "qrel" in opts:       # -qrel: every rank passes the judgments of ITS lists (tests/test_gpu_dist.py external_judgments is the same rule)
+        qb, qe = D.partition_queries(qoff, world)[rank]
+        qi = np.arange(qb, qe)
+        g.set_external_judgments(False, ideal_dcg=np.where(qi % 3 == 0, 10.0 + (qi % 7), np.nan), rel_doc_count=(qi % 4).astype(np.int32))
     if "valid" in opts:
         Xv, lv, qv = synth.make_dataset(n_docs // 3, n_feat, kind, seed_offset=seed + 77)
         lv = lv[::-1].copy()                  # labels unrelated to the features: the validation metric wanders and the early stop fires
@@ -46,7 +53,7 @@ def main():
             dist.destroy_process_group()
             return
     else:
-        g.dist_init_callback(rank, world, tr.allreduce, tr.allgather)
+        g.dist_init_callback(rank, world, tr.allreduce, tr.allgather, None if "noa2a" in opts else tr.alltoallv)
     g.init()
     trees, mets, vmets = [], [], []
     for _ in range(rounds):

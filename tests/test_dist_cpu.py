@@ -69,17 +69,65 @@ assert m.view(np.float64)[0] == 1.5 + world - 1
 # 3. all-gather keeps rank order
 g = tr.allgather(np.full(5, rank, np.uint8))
 assert list(g) == [r for r in range(world) for _ in range(5)]
+# 4. the leaf-owner exchange (ranklib_amd/dist.py leaf_exchange_plan = what rl_trainer.hip does per round): documents of a global data set
+#    live on the ranks in contiguous ascending ranges; every leaf's values must reach its owner in global document order
+rg = np.random.RandomState(7)
+Ndoc, L = 5000, 9
+leaf_of = rg.randint(0, L - 2, Ndoc)                 # two leaf slots stay empty
+val = rg.rand(Ndoc, 2)                                # (lambda, weight) per document
+cut = [0] + sorted(rg.choice(np.arange(1, Ndoc), world - 1, replace=False).tolist()) + [Ndoc]
+lens = [[int(np.sum(leaf_of[cut[r]:cut[r + 1]] == l)) for l in range(L)] for r in range(world)]
+own, send, recv = D.leaf_exchange_plan(lens, rank)
+loads = [sum(sum(lens[r][l] for r in range(world)) for l in range(L) if own[l] == o) for o in range(world)]
+big = max(sum(lens[r][l] for r in range(world)) for l in range(L))
+assert max(loads) <= max(big, -(-Ndoc // world) + big), (loads, big)          # LPT bound: no worse than the mean plus the largest leaf
+mine = np.arange(cut[rank], cut[rank + 1])
+def block(l):                                         # this rank's block of leaf l: lambda segment, then weight segment
+    d = mine[leaf_of[mine] == l]
+    return np.concatenate([val[d, 0], val[d, 1]])
+sbuf = [np.concatenate([block(l) for l, n in send[d]] + [np.zeros(0)]).view(np.uint8) for d in range(world)]
+got = tr.alltoallv(sbuf, [16 * sum(n for _, n in recv[r]) for r in range(world)])
+for l in range(L):
+    if own[l] != rank:
+        continue
+    lam, w = [], []
+    for r in range(world):
+        buf = got[r].view(np.float64); off = 0
+        for l2, n in recv[r]:
+            if l2 == l:
+                lam.append(buf[off:off + n]); w.append(buf[off + n:off + 2 * n])
+            off += 2 * n
+    d = np.nonzero(leaf_of == l)[0]                   # global document order inside the leaf
+    assert np.array_equal(np.concatenate(lam), val[d, 0]) and np.array_equal(np.concatenate(w), val[d, 1])
+recv_bytes = sum(len(got[r]) for r in range(world) if r != rank)
+assert recv_bytes <= 16 * max(loads)                  # never the 16 * Ndoc * (world - 1) / world an all-gather of every document would deliver ... unless one leaf is that big
 dist.barrier()
 sys.stdout.write("ok%d\n" % rank); sys.stdout.flush()
 '''
 
 
-def test_host_transport_over_gloo_world_size_2(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_host_transport_over_gloo(world, tmp_path):
     script = tmp_path / "w.py"
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29507", str(script), ROOT]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29505 + world), str(script), ROOT]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "ok0" in r.stdout and "ok1" in r.stdout
+    assert all(("ok%d" % k) in r.stdout for k in range(world))
+
+
+def test_leaf_owners_are_balanced_and_rank_invariant():
+    rg = np.random.RandomState(3)
+    for R in (1, 2, 3, 8):
+        for _ in range(50):
+            glen = (rg.pareto(1.2, 31) * 1000).astype(np.int64)
+            glen[rg.randint(0, 31, 4)] = 0
+            own = D.leaf_owners(glen, R)
+            assert own == D.leaf_owners(list(glen), R) and all(0 <= o < R for o in own)
+            load = [int(sum(glen[l] for l in range(31) if own[l] == o)) for o in range(R)]
+            assert max(load) <= max(int(glen.max()), -(-int(glen.sum()) // R) + int(glen.max()))

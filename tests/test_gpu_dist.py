@@ -20,10 +20,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def single(n_docs, n_feat, kind, seed, leaves, rounds, dist_mode=None, ranker="LAMBDAMART", metric="NDCG", k=10):
+def single(n_docs, n_feat, kind, seed, leaves, rounds, dist_mode=None, ranker="LAMBDAMART", metric="NDCG", k=10, opts=()):
     X, lab, qoff = synth.make_dataset(n_docs, n_feat, kind, seed_offset=seed)
-    g = N.Trainer(n_trees=rounds, n_leaves=leaves, ranker=ranker, metric=metric, metric_k=k)
+    g = N.Trainer(n_trees=rounds, n_leaves=-1 if "leafm1" in opts else leaves, ranker=ranker, metric=metric, metric_k=k,
+                  min_leaf_support=40 if "leafm1" in opts else 1)
     g.set_train(X, lab, qoff)
+    if "qrel" in opts:       # as tests/dist_worker.py
+        qi = np.arange(len(qoff) - 1)
+        g.set_external_judgments(False, ideal_dcg=np.where(qi % 3 == 0, 10.0 + (qi % 7), np.nan), rel_doc_count=(qi % 4).astype(np.int32))
     if dist_mode == "rccl1":
         g.dist_init(g.dist_unique_id(), 0, 1)
     elif dist_mode == "cb1":
@@ -89,6 +93,52 @@ def test_k_shards_equal_one_shard(world, ranker, metric, k, cfg, tmp_path):
     rounds = CFG[5]
     trees = [{k: z["t%d_%s" % (i, k)] for k in ("feature", "threshold", "left", "right", "output", "deviance", "count")} for i in range(rounds)]
     same(ref, (trees, [float(v) for v in z["mets"]], z["scores"], float(z["final"])))
+    # the leaf-owner exchange: lambda / weight reach the leaf's owner only.  Rank 0 receives, per round, at most 16 bytes for every document
+    # of the leaves it owns that lives elsewhere -- never the 16 N of an all-gather of every document -- and the all-gathers that remain
+    # (leaf tables, 2 L float sums, per-query metric values) are small change
+    st = z["dist_stats"].astype(np.float64)
+    assert st[4] == rounds and st[5] > 0
+    assert st[5] / rounds <= 16.0 * CFG[0] * (world - 1) / world * 0.95, st
+    assert st[3] / rounds <= 0.25 * 16.0 * CFG[0], st
+
+
+@pytest.mark.parametrize("world,metric,k,opt", [(2, "NDCG", 10, "noa2a"), (3, "NDCG", 10, "leafm1"), (2, "NDCG", 10, "qrel"), (3, "MAP", 0, "qrel")])
+def test_sharded_options(world, metric, k, opt, tmp_path):
+    """noa2a: a host transport WITHOUT an all-to-all (the exchange is emulated with all-gathers); leafm1: -leaf -1 (the leaf budget comes from the
+    GLOBAL document count); qrel: external relevance judgments, every rank passing the entries of its own lists -- each equals the one-GPU run"""
+    cfg = (9000, 16, "mslr", 5, 10, 4)
+    ref = single(*cfg, metric=metric, k=k, opts=(opt,))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = str(tmp_path / "o.npz")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29551 + world), os.path.join(ROOT, "tests", "dist_worker.py"), out] + [str(v) for v in cfg] + ["LAMBDAMART", metric, str(k), opt]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    z = np.load(out)
+    trees = [{kk: z["t%d_%s" % (i, kk)] for kk in ("feature", "threshold", "left", "right", "output", "deviance", "count")} for i in range(cfg[5])]
+    same(ref, (trees, [float(v) for v in z["mets"]], z["scores"], float(z["final"])))
+    if opt == "leafm1":
+        assert max(len(t["feature"]) for t in trees) > 2 * cfg[4] - 1, "the trees never outgrew the explicit leaf budget: -leaf -1 was not exercised"
+
+
+def test_bench_entry_starts_its_own_ranks():
+    """`python bench.py --gpus 2` AS TYPED (no launcher around it): the script re-executes itself under torch.distributed.run with two ranks.  Both
+    share the one GPU of the test box through the host-callback transport (RLHIP_BENCH_TRANSPORT=gloo RLHIP_BENCH_SAME_GPU=1; RCCL refuses
+    two ranks on one device) -- the N > 1 path of the driver's scaling run, byte counters included."""
+    import json
+    env = dict(os.environ, RLHIP_BENCH_TRANSPORT="gloo", RLHIP_BENCH_SAME_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    for extra in ([], ["--scaling", "weak"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--shape", "c0", "--plain"] + extra,
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        o = json.loads(lines[0])
+        assert o["n_gpus"] == 2 and o["value"] > 0 and o["scaling"] == ("weak" if extra else "strong")
+        ex = o["config"]["exchange_per_round_rank0"]
+        assert ex["alltoall_calls"] == 1 and 0 < ex["alltoall_bytes_received"] < ex["allgather_of_every_lambda_would_be_bytes"]
+        assert o["config"]["docs_total"] == (20000 if extra else 10000)
 
 
 def _run_workers(world, cfg, out, extra, port):
