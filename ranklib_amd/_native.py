@@ -336,7 +336,7 @@ class Trainer:
             except Exception as e:          # noqa: BLE001
                 print("host all-to-all callback failed:", e)
                 return 1
-        self._cb = (HOST_ALLREDUCE(_ar), HOST_ALLGATHER(_ag), HOST_ALLTOALLV(_aa) if alltoallv is not None else None)      # keep alive
+        self._cb = (HOST_ALLREDUCE(_ar), HOST_ALLGATHER(_ag), HOST_ALLTOALLV(_aa) if alltoallv is not None else HOST_ALLTOALLV())      # keep alive; HOST_ALLTOALLV() is a NULL pointer
         check(lib().rl_dist_init_callback(self.h, rank, n_ranks, self._cb[0], self._cb[1], self._cb[2], None))
 
     def init(self):

@@ -1725,7 +1725,8 @@ int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes)
     case RL_ARR_STEP_LOG: {
         bytes = ((size_t)8 + 8 * kStepLogCap) * sizeof(int32_t);
         if ((int64_t)bytes > cap_bytes) return fail(RL_ERR_INVALID, "output buffer too small");
-        if (c.steplog) RL_HIP(hipMemcpy(out, c.steplog, bytes, hipMemcpyDeviceToHost)); else memset(out, 0, bytes);
+        if (c.steplog) { RL_HIP(hipMemcpy(out, c.steplog, bytes, hipMemcpyDeviceToHost)); RL_HIP(hipMemset(c.steplog, 0, 32)); }      // reading empties the log
+        else memset(out, 0, bytes);
         return RL_OK;
     }
     case RL_ARR_PHASE_CLOCKS: src = c.clk; bytes = 64 * 16 * sizeof(long long); break;

@@ -99,7 +99,8 @@ def test_k_shards_equal_one_shard(world, ranker, metric, k, cfg, tmp_path):
     st = z["dist_stats"].astype(np.float64)
     assert st[4] == rounds and st[5] > 0
     assert st[5] / rounds <= 16.0 * CFG[0] * (world - 1) / world * 0.95, st
-    assert st[3] / rounds <= 0.25 * 16.0 * CFG[0], st
+    # (st[3], the all-gather bytes, also holds rl_init's one-off exchange of the distinct-value sets; the per-round figure is checked through
+    # bench.py's counters in test_bench_entry_starts_its_own_ranks)
 
 
 @pytest.mark.parametrize("world,metric,k,opt", [(2, "NDCG", 10, "noa2a"), (3, "NDCG", 10, "leafm1"), (2, "NDCG", 10, "qrel"), (3, "MAP", 0, "qrel")])
@@ -138,6 +139,7 @@ def test_bench_entry_starts_its_own_ranks():
         assert o["n_gpus"] == 2 and o["value"] > 0 and o["scaling"] == ("weak" if extra else "strong")
         ex = o["config"]["exchange_per_round_rank0"]
         assert ex["alltoall_calls"] == 1 and 0 < ex["alltoall_bytes_received"] < ex["allgather_of_every_lambda_would_be_bytes"]
+        assert ex["allgather_bytes_received"] < 0.5 * ex["allgather_of_every_lambda_would_be_bytes"]      # leaf tables, 2 L float sums, per-query metric values
         assert o["config"]["docs_total"] == (20000 if extra else 10000)
 
 

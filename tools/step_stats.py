@@ -25,11 +25,11 @@ def main():
     g.init()
     if skip:
         g.boost_rounds_async(skip); g.sync()
-    base = int(g.array("STEP_LOG")[0])
+    g.array("STEP_LOG")                      # reading empties the log
     g.boost_rounds_async(rounds); g.sync()
     log = g.array("STEP_LOG")
     n = min(int(log[0]), 8192)
-    e = log[8:8 + 8 * n].reshape(n, 8)[min(base, n):]
+    e = log[8:8 + 8 * n].reshape(n, 8)
     steps, ties = e[e[:, 1] == 0], e[e[:, 1] == 1]
     trees = len(np.unique(e[:, 0]))
     print("%s: %d docs, %d rounds logged (%d entries%s)" % (shape, n_docs, trees, len(e), ", LOG FULL" if int(log[0]) > 8192 else ""))
@@ -52,7 +52,10 @@ def main():
     ns = int(np.sum(g.array("GROW_STATS")[2]))
     print("committed splits with a tied best candidate: %d in %d rounds (%.2f per round)" % (len(ties), trees, len(ties) / max(trees, 1)))
     if len(ties):
-        need = ties[(ties[:, 2] == 2) | (ties[:, 3] == 1)]
+        need = ties[(ties[:, 2] == 2) | ((ties[:, 3] & 1) == 1)]
+        print("  tie kinds: %d plateaus of one feature (%d of them in right children), %d across features (lanes of 32 holding a tied feature: median %d max %d)" %
+              (np.sum(ties[:, 2] == 1), np.sum((ties[:, 2] == 1) & ((ties[:, 3] & 1) == 1)), np.sum(ties[:, 2] == 2),
+               np.median(ties[ties[:, 2] == 2, 3] >> 1) if np.any(ties[:, 2] == 2) else 0, (ties[ties[:, 2] == 2, 3] >> 1).max() if np.any(ties[:, 2] == 2) else 0))
         print("  of those the Java's noise decides (several features tie, or a plateau in a right child): %d (%.2f per round)" % (len(need), len(need) / trees))
         for name, col in (("documents of the node", 4), ("largest node of the derivation chain", 5), ("nodes in the chain", 6), ("documents in the chain", 7)):
             if len(need):
