@@ -84,6 +84,9 @@ struct TreeState {
                                               // select_step calls in this tree; trees started (both mirrored by the host, see Ctx::progress)
     unsigned long long maxabs_bits;   // max |lambda| of the round (bit pattern, monotone for x >= 0)
     long long root_sq;                // sum over all docs of rint(lambda^2 * 2^E2)
+    // lazy tie-break (rl_tie.inc): nodes select_step wanted to partition whose exactly tied best split the Java's rounding noise decides; while
+    // stall_n > 0 the step has no slots (every growth kernel is a no-op) and the host runs the resolution kernels
+    int32_t stall_n, stall_node[kSpec], stall_pad[3 + (4 - kSpec % 4) % 4];
     SlotRec slot[kSpec];
     int32_t arrive1[kSpec][16];        // first-level arrival counters of k_hist_finish (<= 16 feature groups per slot)
 };
@@ -106,6 +109,7 @@ struct Ctx {
                                   // 2 = ((sum >> 44) << 32 | count, low limb) when the data set has fewer than 2^25 documents
     int32_t fs_size;              // features a split attempt looks at: F, or (int)(rate * F) with feature sampling (Random Forests)
     unsigned long long seed;      // rl_params.seed
+    int32_t tie_on;          // lazy Java-order tie-break (rl_tie.inc): one GPU, no feature sampling, not the strict mode
     int32_t mart, metric;    // MART leaf rule (learning/tree/MART.java); RL_METRIC_* of the train metric
     long long *dist_buf;     // [kSpec][F*TS*3 + 4] int64 limbs of the histograms being all-reduced (multi-GPU only)
     // static per data set

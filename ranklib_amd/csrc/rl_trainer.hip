@@ -21,6 +21,7 @@
 #include "rl_kernels_round.inc"
 #include "rl_java_order.inc"
 #include "rl_csc.inc"
+#include "rl_tie.inc"
 #include "rl_membench.inc"
 #include "rl_dist.inc"
 #include "rl_model.h"
@@ -95,6 +96,7 @@ struct rl_trainer {
     unsigned long long *h_progress = nullptr; uint32_t tree_seq = 0; int32_t step_ahead = 3;
     unsigned long long chain_seq = 0; std::vector<void *> pinned;     // chain pass tags; pinned words of the chains (freed in rl_destroy)
     int32_t synced_rounds = 0;
+    long long tie_stalls = 0, tie_nodes = 0, tie_chain_nodes = 0, tie_chain_docs = 0;      // lazy tie-break (rl_tie.inc): resolutions run, nodes resolved, chain nodes / documents summed
     int32_t n_kept = 0;         // trees kept after rollback (== round until rl_finish)
     int32_t best_round = 2147483647 - 2;     // LambdaMART.bestModelOnValidation  LambdaMART.java:50
     double best_score = 0.0;                 // Ranker.bestScoreOnValidationData  Ranker.java:43
@@ -430,6 +432,92 @@ static int gather_queries(rl_trainer *t, const double *local, const double **out
     return RL_OK;
 }
 
+// Lazy Java-order tie-break (rl_tie.inc): the device stalled the tree on nodes whose exactly tied best split the Java's rounding noise decides.
+// The stream is idle when this runs (the caller synchronised it).  Reads the node records, lays out the derivation chains -- a node the Java
+// accumulates (root / left child) is summed from its members; a right child is parent - left sibling, recursively -- and runs the kernels that
+// put the Java's choice into the node records and resume the growth bookkeeping.  Everything is allocated for the call and freed after it:
+// stalls are rare.
+static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds)
+{
+    Ctx &c = t->ctx;
+    hipStream_t s = t->stream;
+    TreeState st;
+    RL_HIP(hipMemcpy(&st, c.st, sizeof(st), hipMemcpyDeviceToHost));
+    if (st.stall_n <= 0 || st.stall_n > kSpec) return fail(RL_ERR_STATE, "resolve_ties without a stalled tree (internal error)");
+    std::vector<NodeRec> nodes((size_t)st.n_nodes);
+    RL_HIP(hipMemcpy(nodes.data(), c.nodes, nodes.size() * sizeof(NodeRec), hipMemcpyDeviceToHost));
+    std::vector<TieNode> an; std::vector<TiePred> preds; std::map<int, int> a_of;
+    auto is_right = [&](int x) { return nodes[x].parent >= 0 && nodes[nodes[x].parent].pr == x; };
+    auto direct = [&](int x) -> int {        // chain node of a directly accumulated node, with the split predicates of its path from the root
+        auto it = a_of.find(x);
+        if (it != a_of.end()) return it->second;
+        TieNode A; A.node = x; A.pred0 = (int)preds.size(); A.npred = 0; A.is_root = (x == 0) ? 1 : 0; A.list0 = 0; A.count = nodes[x].gcount;
+        for (int ch = x; nodes[ch].parent >= 0; ch = nodes[ch].parent) {
+            const NodeRec &P = nodes[nodes[ch].parent];
+            preds.push_back(TiePred{P.best_f, P.best_t, P.pl == ch ? 1 : 0});
+            A.npred++;
+        }
+        an.push_back(A);
+        a_of[x] = (int)an.size() - 1;
+        return (int)an.size() - 1;
+    };
+    const int nx = st.stall_n;
+    std::vector<std::vector<int>> chains((size_t)nx);
+    size_t chain_cap = 1;
+    for (int x = 0; x < nx; x++) {
+        // J(X): X itself when the Java accumulates it; else J(parent) - J(left sibling), the parent first (top-down)
+        std::vector<int> subs;               // left siblings, bottom-up
+        int cur = st.stall_node[x];
+        while (is_right(cur)) { subs.push_back(nodes[nodes[cur].parent].pl); cur = nodes[cur].parent; }
+        chains[x].push_back(direct(cur));
+        for (auto it = subs.rbegin(); it != subs.rend(); ++it) chains[x].push_back(direct(*it));
+        chain_cap = std::max(chain_cap, chains[x].size());
+    }
+    const int nA = (int)an.size();
+    if (nA > kTieMaxChain) return fail(RL_ERR_UNSUPPORTED, "tie-break: derivation chain of " + std::to_string(nA) + " nodes");
+    size_t list_total = 0;
+    for (auto &A : an) if (!A.is_root) { A.list0 = (int32_t)list_total; list_total += (size_t)A.count; }
+    if (list_total > ((size_t)1 << 31) - 1) return fail(RL_ERR_UNSUPPORTED, "tie-break: member lists beyond 2^31 entries");
+    std::vector<int32_t> xlen((size_t)nx), xchain((size_t)nx * chain_cap, 0), xnode((size_t)nx);
+    for (int x = 0; x < nx; x++) {
+        xnode[x] = st.stall_node[x]; xlen[x] = (int32_t)chains[x].size();
+        for (size_t i = 0; i < chains[x].size(); i++) xchain[(size_t)x * chain_cap + i] = chains[x][i];
+    }
+    const int tiles = (c.N + kTieTile - 1) / kTieTile, nbg = (c.TS + 63) / 64;
+    DevPool pool;                            // freed when this call returns
+    TieArgs a; memset(&a, 0, sizeof(a));
+    a.nx = nx; a.nA = nA; a.chain_cap = (int32_t)chain_cap;
+    int32_t *d_xnode = nullptr, *d_xlen = nullptr, *d_xchain = nullptr; TiePred *d_preds = nullptr;
+    RL_HIP(pool.alloc(&d_xnode, (size_t)nx)); RL_HIP(pool.alloc(&d_xlen, (size_t)nx)); RL_HIP(pool.alloc(&d_xchain, xchain.size()));
+    RL_HIP(pool.alloc(&a.an, (size_t)nA)); RL_HIP(pool.alloc(&d_preds, preds.size() + 1));
+    RL_HIP(pool.alloc(&a.tmask, (size_t)nx * c.F * c.TS)); RL_HIP(pool.alloc(&a.need, (size_t)nA * c.F));
+    RL_HIP(pool.alloc(&a.tile_cnt, (size_t)nA * tiles)); RL_HIP(pool.alloc(&a.list, list_total + 1));
+    RL_HIP(pool.alloc(&a.jbin, (size_t)nA * c.F * c.TS)); RL_HIP(pool.alloc(&a.jtot, (size_t)nA));
+    RL_HIP(hipMemcpy(d_xnode, xnode.data(), nx * sizeof(int32_t), hipMemcpyHostToDevice));
+    RL_HIP(hipMemcpy(d_xlen, xlen.data(), nx * sizeof(int32_t), hipMemcpyHostToDevice));
+    RL_HIP(hipMemcpy(d_xchain, xchain.data(), xchain.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    RL_HIP(hipMemcpy(a.an, an.data(), nA * sizeof(TieNode), hipMemcpyHostToDevice));
+    if (!preds.empty()) RL_HIP(hipMemcpy(d_preds, preds.data(), preds.size() * sizeof(TiePred), hipMemcpyHostToDevice));
+    RL_HIP(hipMemsetAsync(a.need, 0, (size_t)nA * c.F * sizeof(int32_t), s));
+    RL_HIP(hipMemsetAsync(a.jbin, 0, (size_t)nA * c.F * c.TS * sizeof(double), s));
+    a.xnode = d_xnode; a.xlen = d_xlen; a.xchain = d_xchain; a.preds = d_preds;
+    hipLaunchKernelGGL(k_tie_cand, dim3(c.F, nx), dim3(kFinThreads), 0, s, c, a);
+    bool any_list = false;
+    for (auto &A : an) any_list |= !A.is_root;
+    if (any_list) {
+        hipLaunchKernelGGL(k_tie_count, dim3(tiles, nA), dim3(kThreads), 0, s, c, a, tiles);
+        hipLaunchKernelGGL(k_tie_scan, dim3(nA), dim3(kThreads), 0, s, a, tiles);
+        hipLaunchKernelGGL(k_tie_scatter, dim3(tiles, nA), dim3(kThreads), 0, s, c, a, tiles);
+    }
+    hipLaunchKernelGGL(k_tie_jsum, dim3(c.F, nbg + 1, nA), dim3(64), 0, s, c, a, nbg);
+    hipLaunchKernelGGL(k_tie_finish, dim3(1), dim3(kFinThreads), fin_lds, s, c, a, nodes_in_lds);
+    RL_HIP(hipGetLastError());
+    RL_HIP(hipStreamSynchronize(s));
+    t->tie_stalls++; t->tie_nodes += nx; t->tie_chain_nodes += nA;
+    for (auto &A : an) t->tie_chain_docs += A.count;
+    return RL_OK;
+}
+
 static int enqueue_round(rl_trainer *t)
 {
     Ctx &c = t->ctx;
@@ -520,7 +608,36 @@ static int enqueue_round(rl_trainer *t)
     const size_t slot_words = (size_t)c.F * c.TS * c.limb_words + 4;
     t->tree_seq++;
     bool throttle = c.progress != nullptr;
-    for (int it = 0; it < steps; it++) {
+    // lazy tie-break (rl_tie.inc): the device may STALL the tree (no slots, progress word bit 31) until resolve_ties has run.  Growth kernels
+    // enqueued meanwhile are no-ops; afterwards the host carries on from the device's own step count.  `extra`: the stalled select_step call and
+    // its resumption count as steps of the device without committing a split.
+    const auto stalled = [&](unsigned long long w) { return c.tie_on && (w >> 32) == t->tree_seq && ((w >> 31) & 1ull); };
+    int extra = 0, it = 0;
+    bool saw_end = false;
+    auto after_stall = [&](bool &ended) -> int {        // stream idle, tree stalled: resolve, then continue at the device's step
+        int rcs = resolve_ties(t, fin_lds, nodes_in_lds);
+        if (rcs) return rcs;
+        extra += 2;
+        TreeState sth;
+        RL_HIP(hipMemcpy(&sth, c.st, sizeof(sth), hipMemcpyDeviceToHost));
+        ended = sth.done != 0;
+        it = sth.step;
+        return RL_OK;
+    };
+  grow:
+    for (; it < steps + extra; it++) {
+        if (throttle && c.tie_on && !t->dist) {
+            const unsigned long long w0 = __atomic_load_n(t->h_progress, __ATOMIC_ACQUIRE);
+            if (stalled(w0)) {
+                RL_HIP(hipStreamSynchronize(s));
+                bool ended = false;
+                int rcs = after_stall(ended);
+                if (rcs) return rcs;
+                if (ended) { saw_end = true; break; }
+                it--;
+                continue;
+            }
+        }
         if (throttle && it >= t->step_ahead) {
             // wait (bounded) until growth step it - step_ahead has been selected, then look at the tree's done flag.  Purely a
             // scheduling hint: on a timeout the remaining steps are enqueued blindly, which is always correct.
@@ -546,7 +663,7 @@ static int enqueue_round(rl_trainer *t)
                                                      " of tree " + std::to_string(t->tree_seq) + " (a rank of the job is missing from a collective?)");
                     }
                 }
-                const int step_w = (int)((unsigned)(w & 0xffffffffull) >> 1);
+                const int step_w = (int)((unsigned)(w & 0x7fffffffull) >> 1);
                 if (finished(w) && step_w <= it - t->step_ahead) break;
             } else if (w < want && !finished(w)) {
                 const auto t0 = std::chrono::steady_clock::now();
@@ -555,7 +672,8 @@ static int enqueue_round(rl_trainer *t)
                     if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) { throttle = false; break; }
                 }
             }
-            if (!t->dist && finished(w)) break;
+            if (!t->dist && stalled(w)) { it--; continue; }       // handled at the top of the loop
+            if (!t->dist && finished(w)) { saw_end = true; break; }
         }
         if (t->dist) {      // local child sizes are unknown in advance: count pass, then scatter
             hipLaunchKernelGGL(k_part_count, dim3(c.nTiles), dim3(kThreads), 0, s, c);
@@ -588,6 +706,19 @@ static int enqueue_round(rl_trainer *t)
             else hipLaunchKernelGGL(k_jhist, dim3(c.n_live, jbg + 2, kSpec), dim3(64), 0, s, c, 0, jbg);
             hipLaunchKernelGGL((k_hist_finish<false, false, true>), dim3(c.n_live, kSpec), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
         } else hipLaunchKernelGGL((k_hist_finish<false, false>), dim3(c.n_live, kSpec), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
+    }
+    if (c.tie_on && !saw_end) {
+        // every step was enqueued without the host ever seeing the end of the tree (no progress word, a spin timeout, or a tree of fewer steps
+        // than the host keeps in flight): a stall may have gone unnoticed -- look, once per round
+        RL_HIP(hipStreamSynchronize(s));
+        TreeState sth;
+        RL_HIP(hipMemcpy(&sth, c.st, sizeof(sth), hipMemcpyDeviceToHost));
+        if (sth.stall_n > 0) {
+            bool ended = false;
+            int rcs = after_stall(ended);
+            if (rcs) return rcs;
+            if (!ended) goto grow;
+        }
     }
     hipLaunchKernelGGL(k_leaf_table, dim3(1), dim3(kThreads), 0, s, c, t->leaf_chain, t->d_seg_buf);
     if (t->p.flags & RL_FLAG_SERIAL_CHAIN) {
@@ -993,6 +1124,10 @@ int rl_init(rl_trainer *t)
     if (const char *e = getenv("RLHIP_NODE_DIV")) c.node_div = std::max(1, atoi(e));          // tuning knobs (tools/), not API
     if (const char *e = getenv("RLHIP_NODE_MIN")) c.node_min = std::max(256, atoi(e) & ~255);
     c.metric = t->p.metric; c.mart = (t->p.ranker == RL_RANKER_MART) ? 1 : 0;
+    // lazy Java-order tie-break (rl_tie.inc): the default path's exact ties resolved as the Java's summation order resolves them.  Not with
+    // feature sampling (the Java's draw is unseeded: nothing to match), not sharded (the Java's order is ONE sequence over all documents), not in
+    // the strict mode (every candidate already comes from the Java-order histogram)
+    c.tie_on = (c.fs_size == F && !t->dist && !(t->p.flags & RL_FLAG_JAVA_ORDER) && !getenv("RLHIP_TIE_OFF")) ? 1 : 0;
     // rows of a ranked list whose pairs the lambda loop visits (LambdaMART.java:375-377: j <= cutoff or k <= cutoff); for
     // NDCG / DCG / ERR row `cutoff` itself only holds zero swap changes
     c.k = (t->p.metric == RL_METRIC_MAP) ? t->p.metric_k + 1 : t->p.metric_k;
@@ -1718,6 +1853,12 @@ int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes)
     case RL_ARR_GROW_DOCS: src = c.grow_docs; bytes = 32; break;
     case RL_ARR_SPARSE_INFO: {
         const int64_t v[4] = {c.sp_on ? c.sp_ngroups : 0, t->sp_entries, c.sp_on ? c.numFG - c.sp_ngroups : c.numFG, t->sp_cols};
+        if (cap_bytes < (int64_t)sizeof(v)) return fail(RL_ERR_INVALID, "output buffer too small");
+        memcpy(out, v, sizeof(v));
+        return RL_OK;
+    }
+    case RL_ARR_TIE_STATS: {
+        const int64_t v[4] = {t->tie_stalls, t->tie_nodes, t->tie_chain_nodes, t->tie_chain_docs};
         if (cap_bytes < (int64_t)sizeof(v)) return fail(RL_ERR_INVALID, "output buffer too small");
         memcpy(out, v, sizeof(v));
         return RL_OK;
