@@ -97,15 +97,14 @@ def test_fullsize_determinism_c1():
             assert np.array_equal(x["tree"][k], y["tree"][k])
 
 
-@pytest.mark.parametrize("shape,rounds", [("c1", 3), ("c2", 3)])
-def test_fullsize_oracle_parity(shape, rounds):
+@pytest.mark.parametrize("shape,rounds,strict", [("c1", 3, False), ("c2", 3, False), ("c1", 2, True), ("c2", 2, True)])
+def test_fullsize_oracle_parity(shape, rounds, strict):
     """c1 / c2 against the CPU oracle run with RankLib's MyThreadPool work split on every host thread
     (learning/tree/LambdaMART.java:169-272): thresholds, bins, root counts at init; lambda, weight, scores, per-round metric
-    bit for bit; trees through tree_equiv (prints how many of the compared splits were exact-arithmetic ties that the two sides
-    resolved differently).  With RLHIP_TEST_JAVA_ORDER=1 the GPU runs RL_FLAG_JAVA_ORDER and the tie count must be 0."""
+    bit for bit; trees through tree_equiv, and NO split may store another (feature, threshold) than the oracle's -- with the default flags
+    (exact ties are re-decided in the Java's summation order, rl_tie.inc) and in the strict mode (RL_FLAG_JAVA_ORDER)."""
     n_docs, n_feat, kind, _, n_leaves = synth.SHAPES[shape]
     X, lab, qoff, Q = synth.make_shard(n_docs, n_feat, kind, 0, 1)
-    strict = os.environ.get("RLHIP_TEST_JAVA_ORDER", "0") == "1"
     t0 = time.time()
     o = O.Oracle(X, lab, qoff, n_trees=rounds, n_leaves=n_leaves, n_threads=os.cpu_count() or 8)
     o.init()
@@ -136,5 +135,5 @@ def test_fullsize_oracle_parity(shape, rounds):
     print("\n[fullsize parity] %s%s: %d rounds, splits compared %d, tie-resolved differently %d; oracle init %.1f s, %.2f s/round on %d threads"
           % (shape, " (java-order)" if strict else "", rounds, stats.get("splits", 0), stats.get("plateau", 0), t_oinit,
              t_or / rounds, os.cpu_count() or 8))
-    if strict:
-        assert stats.get("plateau", 0) == 0
+    print("[fullsize parity] lazy tie-break: %s (resolutions, nodes, chain nodes, chain documents)" % g.array("TIE_STATS").tolist())
+    assert stats.get("plateau", 0) == 0

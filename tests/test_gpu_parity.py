@@ -39,13 +39,17 @@ STATS = {}
 
 
 def assert_same_tree(to, tg, X, ctx=""):
-    """bit-exact, except the documented plateau tie (tests/tree_equiv.py) which must induce the same partition"""
-    return assert_equivalent(to, tg, X, ctx, STATS)
+    """bit-exact, stored (feature, threshold) pairs included"""
+    ties = assert_equivalent(to, tg, X, ctx, STATS)
+    # the default path on one GPU without feature sampling: exact ties are re-decided in the Java's summation order (rl_tie.inc), so the stored
+    # (feature, threshold) pairs are the oracle's -- no split may be resolved differently (tests with feature sampling call assert_equivalent)
+    assert ties == 0, "%d split(s) store another (feature, threshold) than the oracle's in %s (%s)" % (ties, os.environ.get("PYTEST_CURRENT_TEST", "?"), ctx)
+    return ties
 
 
 def teardown_module(module):
     if STATS:
-        print("\n[parity] splits compared: %d, plateau-tie thresholds (same partition, lower threshold): %d"
+        print("\n[parity] splits compared: %d, stored (feature, threshold) pairs that differ from the oracle's: %d"
               % (STATS.get("splits", 0), STATS.get("plateau", 0)))
 
 
@@ -126,6 +130,9 @@ def test_trees_scores_metrics_bit_exact(n_docs, n_feat, kind, leaves, mls, round
     sg, _ = g.finish()
     assert so == sg
     assert np.array_equal(g.predict(X[:777]).view(np.uint32), o.predict(X[:777]).view(np.uint32))
+    if n_docs == 2500:      # this data set's small nodes hold exact ties in most rounds: the lazy tie-break must have run
+        st = g.array("TIE_STATS")
+        assert st[0] > 0 and st[1] >= st[0] and st[2] >= st[1], st
 
 
 def _eval_tree_rows(tr, X):

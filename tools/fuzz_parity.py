@@ -105,7 +105,8 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1          # multiplies the number of lists (bigger data: several chunks / tiles per node)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = ties = skipped = 0
-reasons = {}
+other_splits = compared_splits = 0        # splits that store another (feature, threshold) than the oracle's while the trees stay equivalent (exact-tie plateaus): 0 with
+reasons = {}                              # the lazy Java-order tie-break (rl_tie.inc) unless features are sampled
 for case in range(n_cases):
     F = int(rng.choice([3, 8, 17, 40]))
     kind = rng.choice(["tiny", "mixed", "long"])
@@ -174,6 +175,8 @@ for case in range(n_cases):
             assert np.array_equal(g.array("LAMBDA"), lam), "lambda, round %d" % m
             try:
                 nt = assert_equivalent(to, tg, X, ctx="round %d" % m)
+                if frate >= 1.0 and not os.environ.get("FUZZ_DIST"):
+                    other_splits += nt; compared_splits += int((to.trimmed()["feature"] != -1).sum())
                 if JAVA:
                     assert nt == 0, "RL_FLAG_JAVA_ORDER: %d splits store another (feature, threshold) than the oracle's, round %d" % (nt, m)
             except AssertionError:
@@ -183,6 +186,8 @@ for case in range(n_cases):
                 if why:
                     ties += 1
                     reasons[why] = reasons.get(why, 0) + 1
+                    if frate >= 1.0 and os.environ.get("FUZZ_VERBOSE"):
+                        print("  case %d ended in round %d: %s %s" % (case, m, why, desc), flush=True)
                     ended = True
                     break
                 print("  unexplained:", getattr(classify, "last", None), flush=True)
@@ -218,5 +223,6 @@ for case in range(n_cases):
     except Exception as ex:       # noqa: BLE001
         bad += 1
         print("MISMATCH", desc, "->", repr(ex)[:300], flush=True)
-print("%d cases: %d mismatches, %d ended at a tie %s, %d skipped (documented limits)" % (n_cases, bad, ties, reasons, skipped))
+print("%d cases: %d mismatches, %d ended at a tie %s, %d skipped (documented limits); without feature sampling %d of %d compared splits store another "
+      "(feature, threshold) than the oracle's" % (n_cases, bad, ties, reasons, skipped, other_splits, compared_splits))
 sys.exit(1 if bad else 0)
