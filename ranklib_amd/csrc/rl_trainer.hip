@@ -97,6 +97,8 @@ struct rl_trainer {
     unsigned long long chain_seq = 0; std::vector<void *> pinned;     // chain pass tags; pinned words of the chains (freed in rl_destroy)
     int32_t synced_rounds = 0;
     long long tie_stalls = 0, tie_nodes = 0, tie_chain_nodes = 0, tie_chain_docs = 0;      // lazy tie-break (rl_tie.inc): resolutions run, nodes resolved, chain nodes / documents summed
+    long long tie_us = 0, tie_spec_segs = 0, tie_spec_miss = 0, tie_spec_serial = 0, tie_spec_repairs = 0;      // host time in resolve_ties; segments evaluated, window misses, serial segments, repair passes
+    void *tie_buf = nullptr; size_t tie_cap = 0, tie_hint = 0;                                              // scratch arena of resolve_ties (only ever grows)
     int32_t n_kept = 0;         // trees kept after rollback (== round until rl_finish)
     int32_t best_round = 2147483647 - 2;     // LambdaMART.bestModelOnValidation  LambdaMART.java:50
     double best_score = 0.0;                 // Ranker.bestScoreOnValidationData  Ranker.java:43
@@ -435,12 +437,26 @@ static int gather_queries(rl_trainer *t, const double *local, const double **out
 // Lazy Java-order tie-break (rl_tie.inc): the device stalled the tree on nodes whose exactly tied best split the Java's rounding noise decides.
 // The stream is idle when this runs (the caller synchronised it).  Reads the node records, lays out the derivation chains -- a node the Java
 // accumulates (root / left child) is summed from its members; a right child is parent - left sibling, recursively -- and runs the kernels that
-// put the Java's choice into the node records and resume the growth bookkeeping.  Everything is allocated for the call and freed after it:
-// stalls are rare.
+// put the Java's choice into the node records and resume the growth bookkeeping.  Device scratch comes from one arena that only ever grows.
+struct TieArena {
+    char *base = nullptr; size_t cap = 0, used = 0;
+    template <class T> T *take(size_t n) { used = (used + 255) & ~(size_t)255; T *p = (T *)(base + used); used += n * sizeof(T); return p; }
+};
+static int tie_arena_reserve(rl_trainer *t, size_t bytes)
+{
+    if (bytes <= t->tie_cap) return RL_OK;
+    if (t->tie_buf) { (void)hipFree(t->tie_buf); t->tie_buf = nullptr; t->tie_cap = 0; }
+    const size_t want = bytes + bytes / 4 + (1 << 20);
+    if (hipMalloc(&t->tie_buf, want) != hipSuccess) { (void)hipGetLastError(); t->tie_buf = nullptr; return RL_ERR_HIP; }
+    t->tie_cap = want;
+    return RL_OK;
+}
+
 static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds)
 {
     Ctx &c = t->ctx;
     hipStream_t s = t->stream;
+    const auto t_begin = std::chrono::steady_clock::now();
     TreeState st;
     RL_HIP(hipMemcpy(&st, c.st, sizeof(st), hipMemcpyDeviceToHost));
     if (st.stall_n <= 0 || st.stall_n > kSpec) return fail(RL_ERR_STATE, "resolve_ties without a stalled tree (internal error)");
@@ -475,8 +491,15 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds)
     }
     const int nA = (int)an.size();
     if (nA > kTieMaxChain) return fail(RL_ERR_UNSUPPORTED, "tie-break: derivation chain of " + std::to_string(nA) + " nodes");
-    size_t list_total = 0;
-    for (auto &A : an) if (!A.is_root) { A.list0 = (int32_t)list_total; list_total += (size_t)A.count; }
+    size_t list_total = 0, u_total = 0;
+    std::vector<long long> u0((size_t)nA);
+    int maxcnt = 1;
+    for (int i = 0; i < nA; i++) {
+        TieNode &A = an[i];
+        if (!A.is_root) { A.list0 = (int32_t)list_total; list_total += (size_t)A.count; }
+        u0[i] = (long long)u_total; u_total += (size_t)A.count;
+        maxcnt = std::max(maxcnt, A.count);
+    }
     if (list_total > ((size_t)1 << 31) - 1) return fail(RL_ERR_UNSUPPORTED, "tie-break: member lists beyond 2^31 entries");
     std::vector<int32_t> xlen((size_t)nx), xchain((size_t)nx * chain_cap, 0), xnode((size_t)nx);
     for (int x = 0; x < nx; x++) {
@@ -484,37 +507,150 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds)
         for (size_t i = 0; i < chains[x].size(); i++) xchain[(size_t)x * chain_cap + i] = chains[x][i];
     }
     const int tiles = (c.N + kTieTile - 1) / kTieTile, nbg = (c.TS + 63) / 64;
-    DevPool pool;                            // freed when this call returns
-    TieArgs a; memset(&a, 0, sizeof(a));
-    a.nx = nx; a.nA = nA; a.chain_cap = (int32_t)chain_cap;
-    int32_t *d_xnode = nullptr, *d_xlen = nullptr, *d_xchain = nullptr; TiePred *d_preds = nullptr;
-    RL_HIP(pool.alloc(&d_xnode, (size_t)nx)); RL_HIP(pool.alloc(&d_xlen, (size_t)nx)); RL_HIP(pool.alloc(&d_xchain, xchain.size()));
-    RL_HIP(pool.alloc(&a.an, (size_t)nA)); RL_HIP(pool.alloc(&d_preds, preds.size() + 1));
-    RL_HIP(pool.alloc(&a.tmask, (size_t)nx * c.F * c.TS)); RL_HIP(pool.alloc(&a.need, (size_t)nA * c.F));
-    RL_HIP(pool.alloc(&a.tile_cnt, (size_t)nA * tiles)); RL_HIP(pool.alloc(&a.list, list_total + 1));
-    RL_HIP(pool.alloc(&a.jbin, (size_t)nA * c.F * c.TS)); RL_HIP(pool.alloc(&a.jtot, (size_t)nA));
-    RL_HIP(hipMemcpy(d_xnode, xnode.data(), nx * sizeof(int32_t), hipMemcpyHostToDevice));
-    RL_HIP(hipMemcpy(d_xlen, xlen.data(), nx * sizeof(int32_t), hipMemcpyHostToDevice));
-    RL_HIP(hipMemcpy(d_xchain, xchain.data(), xchain.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    RL_HIP(hipMemcpy(a.an, an.data(), nA * sizeof(TieNode), hipMemcpyHostToDevice));
-    if (!preds.empty()) RL_HIP(hipMemcpy(d_preds, preds.data(), preds.size() * sizeof(TiePred), hipMemcpyHostToDevice));
-    RL_HIP(hipMemsetAsync(a.need, 0, (size_t)nA * c.F * sizeof(int32_t), s));
-    RL_HIP(hipMemsetAsync(a.jbin, 0, (size_t)nA * c.F * c.TS * sizeof(double), s));
-    a.xnode = d_xnode; a.xlen = d_xlen; a.xchain = d_xchain; a.preds = d_preds;
-    hipLaunchKernelGGL(k_tie_cand, dim3(c.F, nx), dim3(kFinThreads), 0, s, c, a);
-    bool any_list = false;
-    for (auto &A : an) any_list |= !A.is_root;
-    if (any_list) {
-        hipLaunchKernelGGL(k_tie_count, dim3(tiles, nA), dim3(kThreads), 0, s, c, a, tiles);
-        hipLaunchKernelGGL(k_tie_scan, dim3(nA), dim3(kThreads), 0, s, a, tiles);
-        hipLaunchKernelGGL(k_tie_scatter, dim3(tiles, nA), dim3(kThreads), 0, s, c, a, tiles);
+    // ---- stage 1: fixed-size scratch, the tied candidates, the member lists
+    const size_t fixed_bytes = (size_t)nx * c.F * c.TS + ((size_t)nA * c.F + (size_t)nA * tiles + list_total + 64) * 4 + ((size_t)nA * c.F * c.TS + nA) * 8 +
+                               (xchain.size() + 2 * (size_t)nx + 16) * 4 + (size_t)nA * sizeof(TieNode) + (preds.size() + 1) * sizeof(TiePred) + (size_t)nA * 8 + 64 * 256;
+    if (tie_arena_reserve(t, std::max(fixed_bytes + ((size_t)64 << 20), t->tie_hint))) return fail(RL_ERR_HIP, "tie-break: out of device memory");
+    TieArena ar;
+    TieArgs a;
+    long long *d_u0 = nullptr;
+    std::vector<int32_t> need((size_t)nA * c.F);
+    // (a lambda: when stage 2 turns out to need a larger arena, the arena moves and stage 1 is simply run again)
+    auto stage1 = [&]() -> int {
+        ar = TieArena(); ar.base = (char *)t->tie_buf; ar.cap = t->tie_cap;
+        memset(&a, 0, sizeof(a));
+        a.nx = nx; a.nA = nA; a.chain_cap = (int32_t)chain_cap;
+        int32_t *d_xnode = ar.take<int32_t>(nx), *d_xlen = ar.take<int32_t>(nx), *d_xchain = ar.take<int32_t>(xchain.size());
+        a.an = ar.take<TieNode>(nA); TiePred *d_preds = ar.take<TiePred>(preds.size() + 1);
+        d_u0 = ar.take<long long>(nA);
+        a.tmask = ar.take<uint8_t>((size_t)nx * c.F * c.TS); a.need = ar.take<int32_t>((size_t)nA * c.F);
+        a.tile_cnt = ar.take<int32_t>((size_t)nA * tiles); a.list = ar.take<int32_t>(list_total + 1);
+        a.jbin = ar.take<double>((size_t)nA * c.F * c.TS); a.jtot = ar.take<double>(nA);
+        RL_HIP(hipMemcpyAsync(d_xnode, xnode.data(), nx * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        RL_HIP(hipMemcpyAsync(d_xlen, xlen.data(), nx * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        RL_HIP(hipMemcpyAsync(d_xchain, xchain.data(), xchain.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        RL_HIP(hipMemcpyAsync(a.an, an.data(), nA * sizeof(TieNode), hipMemcpyHostToDevice, s));
+        RL_HIP(hipMemcpyAsync(d_u0, u0.data(), nA * sizeof(long long), hipMemcpyHostToDevice, s));
+        if (!preds.empty()) RL_HIP(hipMemcpyAsync(d_preds, preds.data(), preds.size() * sizeof(TiePred), hipMemcpyHostToDevice, s));
+        RL_HIP(hipMemsetAsync(a.need, 0, (size_t)nA * c.F * sizeof(int32_t), s));
+        a.xnode = d_xnode; a.xlen = d_xlen; a.xchain = d_xchain; a.preds = d_preds;
+        hipLaunchKernelGGL(k_tie_cand, dim3(c.F, nx), dim3(kFinThreads), 0, s, c, a);
+        bool any_list = false;
+        for (auto &A : an) any_list |= !A.is_root;
+        if (any_list) {
+            hipLaunchKernelGGL(k_tie_count, dim3(tiles, nA), dim3(kThreads), 0, s, c, a, tiles);
+            hipLaunchKernelGGL(k_tie_scan, dim3(nA), dim3(kThreads), 0, s, a, tiles);
+            hipLaunchKernelGGL(k_tie_scatter, dim3(tiles, nA), dim3(kThreads), 0, s, c, a, tiles);
+        }
+        RL_HIP(hipMemcpyAsync(need.data(), a.need, need.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        RL_HIP(hipStreamSynchronize(s));
+        return RL_OK;
+    };
+    { int rc1 = stage1(); if (rc1) return rc1; }
+    // ---- stage 2: the needed (chain node, feature) pairs, their bins' sizes, the chains and their segments
+    std::vector<TiePair> pairs;
+    size_t v_total = u_total;
+    int tiles_max = 1;
+    for (int i = 0; i < nA; i++)
+        for (int f = 0; f < c.F; f++)
+            if (need[(size_t)i * c.F + f]) {
+                TiePair P; P.a = i; P.f = f; P.tiles = (an[i].count + kTsTile - 1) / kTsTile; P.pad = 0; P.v0 = (long long)v_total;
+                v_total += (size_t)an[i].count; tiles_max = std::max(tiles_max, P.tiles);
+                pairs.push_back(P);
+            }
+    const int npairs = (int)pairs.size();
+    bool walk = getenv("RLHIP_TIE_WALK") != nullptr || npairs == 0;
+    std::vector<int32_t> cnts((size_t)npairs * c.TS);
+    if (!walk) {       // cumulative bin counts of the pairs (exact): where every bin's run starts in the sorted values
+        for (int p = 0; p < npairs; p++)
+            RL_HIP(hipMemcpyAsync(cnts.data() + (size_t)p * c.TS, c.cum_cnt + ((size_t)an[pairs[p].a].node * c.F + pairs[p].f) * c.TS, (size_t)c.TS * sizeof(int32_t),
+                                  hipMemcpyDeviceToHost, s));
+        RL_HIP(hipStreamSynchronize(s));
     }
-    hipLaunchKernelGGL(k_tie_jsum, dim3(c.F, nbg + 1, nA), dim3(64), 0, s, c, a, nbg);
+    std::vector<TieChain> chs; std::vector<int32_t> seg_chain;
+    auto add_chain = [&](long long off, int len, int out) {
+        TieChain C; C.off = off; C.len = len; C.out = out; C.seg0 = (int32_t)seg_chain.size();
+        C.seglen = std::min(16384, std::max(2048, ((len / 256 + 2047) / 2048) * 2048));
+        const int ns = (len + C.seglen - 1) / C.seglen;
+        for (int j = 0; j < ns; j++) seg_chain.push_back((int32_t)chs.size());
+        chs.push_back(C);
+    };
+    std::vector<int32_t> h_nthr;
+    if (!walk) {
+        h_nthr.resize(c.F);
+        RL_HIP(hipMemcpy(h_nthr.data(), c.nthr, c.F * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int i = 0; i < nA; i++) add_chain(u0[i], an[i].count, -(i + 1));
+        for (int p = 0; p < npairs; p++) {
+            const int32_t *cc = cnts.data() + (size_t)p * c.TS;
+            for (int b = 0; b < h_nthr[pairs[p].f]; b++) {
+                const int start = b > 0 ? cc[b - 1] : 0;
+                add_chain(pairs[p].v0 + start, cc[b] - start, (int)(((size_t)pairs[p].a * c.F + pairs[p].f) * c.TS + b));
+            }
+        }
+    }
+    const int nch = (int)chs.size(), nseg = (int)seg_chain.size();
+    const size_t spec_bytes = v_total * 8 + (size_t)npairs * tiles_max * c.TS * 4 + (size_t)nseg * (16 + 16 + 8 + 8 * kSpW) + (size_t)nch * (16 + 8 + 8 + sizeof(TieChain)) +
+                              (size_t)npairs * sizeof(TiePair) + (size_t)nseg * 4 + 64 * 256;
+    if (!walk && fixed_bytes + spec_bytes + ((size_t)1 << 20) > t->tie_cap) {
+        // the arena has to grow: it moves, so stage 1 runs again in the new one (and later calls ask for this much up front)
+        t->tie_hint = fixed_bytes + spec_bytes + ((size_t)1 << 20);
+        if (tie_arena_reserve(t, t->tie_hint)) {      // no room for the contiguous chains: the literal walk in a minimal arena
+            walk = true;
+            if (tie_arena_reserve(t, fixed_bytes + ((size_t)1 << 20))) return fail(RL_ERR_HIP, "tie-break: out of device memory");
+        }
+        int rc1 = stage1(); if (rc1) return rc1;
+    }
+    if (walk) {
+        RL_HIP(hipMemsetAsync(a.jbin, 0, (size_t)nA * c.F * c.TS * sizeof(double), s));
+        hipLaunchKernelGGL(k_tie_jsum, dim3(c.F, nbg + 1, nA), dim3(64), 0, s, c, a, nbg);
+    } else {
+        SpArgs sp; memset(&sp, 0, sizeof(sp));
+        sp.nchains = nch; sp.nseg = nseg; sp.npairs = npairs; sp.tiles_max = tiles_max;
+        TiePair *d_pairs = ar.take<TiePair>(npairs); TieChain *d_chs = ar.take<TieChain>(nch); int32_t *d_segc = ar.take<int32_t>(nseg + 1);
+        sp.vals = ar.take<double>(v_total + 1); sp.tbin = ar.take<int32_t>((size_t)npairs * tiles_max * c.TS);
+        sp.segsum = ar.take<double2>(nseg + 1); sp.segpre = ar.take<double2>(nseg + 1);
+        sp.centre = ar.take<unsigned long long>(nseg + 1); sp.table = ar.take<unsigned long long>((size_t)nseg * kSpW + 1);
+        sp.cstate = ar.take<int32_t>((size_t)nch * 4); sp.ckey = ar.take<unsigned long long>(nch); sp.cshift = ar.take<long long>(nch);
+        sp.open = ar.take<int32_t>(4);
+        if (ar.used > t->tie_cap) return fail(RL_ERR_HIP, "tie-break: scratch arena too small (internal error)");
+        RL_HIP(hipMemcpyAsync(d_pairs, pairs.data(), npairs * sizeof(TiePair), hipMemcpyHostToDevice, s));
+        RL_HIP(hipMemcpyAsync(d_chs, chs.data(), nch * sizeof(TieChain), hipMemcpyHostToDevice, s));
+        RL_HIP(hipMemcpyAsync(d_segc, seg_chain.data(), nseg * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        sp.pairs = d_pairs; sp.chains = d_chs; sp.seg_chain = d_segc; sp.u0 = d_u0;
+        hipLaunchKernelGGL(k_tie_gather, dim3(std::min(4096, (maxcnt + kThreads - 1) / kThreads), nA), dim3(kThreads), 0, s, c, a, sp);
+        hipLaunchKernelGGL(k_ts_count, dim3(tiles_max, npairs), dim3(64), (size_t)c.TS * 4, s, c, a, sp);
+        hipLaunchKernelGGL(k_ts_scan, dim3(npairs, nbg), dim3(64), 0, s, c, a, sp);
+        hipLaunchKernelGGL(k_ts_scatter, dim3(tiles_max, npairs), dim3(64), (size_t)c.TS * 4, s, c, a, sp);
+        const int cb = (nch + kThreads - 1) / kThreads;
+        if (nseg > 0) hipLaunchKernelGGL(k_sp_sum, dim3(nseg), dim3(64), 0, s, sp);
+        hipLaunchKernelGGL(k_sp_scan, dim3(cb), dim3(kThreads), 0, s, sp);
+        if (nseg > 0) {
+            hipLaunchKernelGGL(k_sp_run<false>, dim3(nseg), dim3(64), 0, s, sp);
+            hipLaunchKernelGGL(k_sp_drift, dim3(cb), dim3(kThreads), 0, s, sp);
+            hipLaunchKernelGGL(k_sp_run<false>, dim3(nseg), dim3(64), 0, s, sp);
+        }
+        int32_t open = 0;
+        for (int rep = 0; rep <= kSpRepairs; rep++) {
+            RL_HIP(hipMemsetAsync(sp.open, 0, sizeof(int32_t), s));
+            hipLaunchKernelGGL(k_sp_stitch, dim3(cb), dim3(kThreads), 0, s, sp, a, rep == kSpRepairs ? 1 : 0);
+            RL_HIP(hipMemcpyAsync(&open, sp.open, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            RL_HIP(hipStreamSynchronize(s));
+            if (open == 0) break;
+            t->tie_spec_repairs++;
+            hipLaunchKernelGGL(k_sp_run<true>, dim3(nseg), dim3(64), 0, s, sp);
+        }
+        std::vector<int32_t> cst((size_t)nch * 4);
+        RL_HIP(hipMemcpyAsync(cst.data(), sp.cstate, cst.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        RL_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < nch; i++) { t->tie_spec_miss += cst[4 * (size_t)i + 1]; t->tie_spec_serial += cst[4 * (size_t)i + 2]; }
+        t->tie_spec_segs += nseg;
+    }
     hipLaunchKernelGGL(k_tie_finish, dim3(1), dim3(kFinThreads), fin_lds, s, c, a, nodes_in_lds);
     RL_HIP(hipGetLastError());
     RL_HIP(hipStreamSynchronize(s));
     t->tie_stalls++; t->tie_nodes += nx; t->tie_chain_nodes += nA;
     for (auto &A : an) t->tie_chain_docs += A.count;
+    t->tie_us += (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_begin).count();
     return RL_OK;
 }
 
@@ -1027,6 +1163,7 @@ void rl_destroy(rl_trainer *t)
     for (auto e : t->ev_free) (void)hipEventDestroy(e);
     if (t->stream) (void)hipStreamDestroy(t->stream);
     if (t->h_progress) (void)hipHostFree(t->h_progress);
+    if (t->tie_buf) (void)hipFree(t->tie_buf);
     for (void *q : t->pinned) (void)hipHostFree(q);
     delete t;
 }
@@ -1858,7 +1995,7 @@ int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes)
         return RL_OK;
     }
     case RL_ARR_TIE_STATS: {
-        const int64_t v[4] = {t->tie_stalls, t->tie_nodes, t->tie_chain_nodes, t->tie_chain_docs};
+        const int64_t v[8] = {t->tie_stalls, t->tie_nodes, t->tie_chain_nodes, t->tie_chain_docs, t->tie_us, t->tie_spec_segs, t->tie_spec_miss, t->tie_spec_serial};
         if (cap_bytes < (int64_t)sizeof(v)) return fail(RL_ERR_INVALID, "output buffer too small");
         memcpy(out, v, sizeof(v));
         return RL_OK;

@@ -49,7 +49,9 @@ def main():
             continue
         print("  step %2d: in %4.0f %% of the trees, slots %.1f, split node median %8d max %8d, accumulated child median %8d" %
               (k, 100.0 * len(np.unique(steps[m, 0])) / trees, m.sum() / max(len(np.unique(steps[m, 0])), 1), np.median(steps[m, 4]), steps[m, 4].max(), np.median(steps[m, 5])))
-    ns = int(np.sum(g.array("GROW_STATS")[2]))
+    ts = g.array("TIE_STATS")
+    print("lazy tie-break over the whole run (skipped rounds included): %d resolutions, %d nodes, %d chain nodes, %d chain documents; %.1f ms on the host, "
+          "%d speculative segments, %d window misses, %d serial segments" % (int(ts[0]), int(ts[1]), int(ts[2]), int(ts[3]), ts[4] / 1e3, int(ts[5]), int(ts[6]), int(ts[7])))
     print("committed splits with a tied best candidate: %d in %d rounds (%.2f per round)" % (len(ties), trees, len(ties) / max(trees, 1)))
     if len(ties):
         need = ties[(ties[:, 2] == 2) | ((ties[:, 3] & 1) == 1)]
