@@ -98,6 +98,7 @@ struct rl_trainer {
     int32_t synced_rounds = 0;
     long long tie_stalls = 0, tie_nodes = 0, tie_chain_nodes = 0, tie_chain_docs = 0;      // lazy tie-break (rl_tie.inc): resolutions run, nodes resolved, chain nodes / documents summed
     long long tie_us = 0, tie_spec_segs = 0, tie_spec_miss = 0, tie_spec_serial = 0, tie_spec_repairs = 0;      // host time in resolve_ties; segments evaluated, window misses, serial segments, repair passes
+    std::vector<int32_t> h_nthr; std::vector<char> tie_blob;
     void *tie_buf = nullptr; size_t tie_cap = 0, tie_hint = 0;                                              // scratch arena of resolve_ties (only ever grows)
     int32_t n_kept = 0;         // trees kept after rollback (== round until rl_finish)
     int32_t best_round = 2147483647 - 2;     // LambdaMART.bestModelOnValidation  LambdaMART.java:50
@@ -508,7 +509,7 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds)
     }
     const int tiles = (c.N + kTieTile - 1) / kTieTile, nbg = (c.TS + 63) / 64;
     // ---- stage 1: fixed-size scratch, the tied candidates, the member lists
-    const size_t fixed_bytes = (size_t)nx * c.F * c.TS + ((size_t)nA * c.F + (size_t)nA * tiles + list_total + 64) * 4 + ((size_t)nA * c.F * c.TS + nA) * 8 +
+    const size_t fixed_bytes = (size_t)nx * c.F * c.TS + ((size_t)nA * c.F + (size_t)nx * c.F + (size_t)nA * tiles + list_total + 64) * 4 + ((size_t)nA * c.F * c.TS + nA) * 8 +
                                (xchain.size() + 2 * (size_t)nx + 16) * 4 + (size_t)nA * sizeof(TieNode) + (preds.size() + 1) * sizeof(TiePred) + (size_t)nA * 8 + 64 * 256;
     if (tie_arena_reserve(t, std::max(fixed_bytes + ((size_t)64 << 20), t->tie_hint))) return fail(RL_ERR_HIP, "tie-break: out of device memory");
     TieArena ar;
@@ -520,18 +521,19 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds)
         ar = TieArena(); ar.base = (char *)t->tie_buf; ar.cap = t->tie_cap;
         memset(&a, 0, sizeof(a));
         a.nx = nx; a.nA = nA; a.chain_cap = (int32_t)chain_cap;
-        int32_t *d_xnode = ar.take<int32_t>(nx), *d_xlen = ar.take<int32_t>(nx), *d_xchain = ar.take<int32_t>(xchain.size());
-        a.an = ar.take<TieNode>(nA); TiePred *d_preds = ar.take<TiePred>(preds.size() + 1);
-        d_u0 = ar.take<long long>(nA);
-        a.tmask = ar.take<uint8_t>((size_t)nx * c.F * c.TS); a.need = ar.take<int32_t>((size_t)nA * c.F);
+        // the small host tables travel as ONE copy
+        std::vector<char> &blob = t->tie_blob; blob.clear();
+        auto put = [&](const void *src, size_t bytes) { const size_t o = (blob.size() + 15) & ~(size_t)15; blob.resize(o + bytes); if (bytes) memcpy(blob.data() + o, src, bytes); return o; };
+        const size_t o_xnode = put(xnode.data(), nx * sizeof(int32_t)), o_xlen = put(xlen.data(), nx * sizeof(int32_t)), o_xchain = put(xchain.data(), xchain.size() * sizeof(int32_t));
+        const size_t o_an = put(an.data(), nA * sizeof(TieNode)), o_preds = put(preds.data(), preds.size() * sizeof(TiePred)), o_u0 = put(u0.data(), nA * sizeof(long long));
+        char *d_blob = ar.take<char>(blob.size() + 16);
+        RL_HIP(hipMemcpyAsync(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, s));
+        int32_t *d_xnode = (int32_t *)(d_blob + o_xnode), *d_xlen = (int32_t *)(d_blob + o_xlen), *d_xchain = (int32_t *)(d_blob + o_xchain);
+        a.an = (TieNode *)(d_blob + o_an); TiePred *d_preds = (TiePred *)(d_blob + o_preds);
+        d_u0 = (long long *)(d_blob + o_u0);
+        a.tmask = ar.take<uint8_t>((size_t)nx * c.F * c.TS); a.need = ar.take<int32_t>((size_t)nA * c.F); a.xf = ar.take<int32_t>((size_t)nx * c.F);
         a.tile_cnt = ar.take<int32_t>((size_t)nA * tiles); a.list = ar.take<int32_t>(list_total + 1);
         a.jbin = ar.take<double>((size_t)nA * c.F * c.TS); a.jtot = ar.take<double>(nA);
-        RL_HIP(hipMemcpyAsync(d_xnode, xnode.data(), nx * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        RL_HIP(hipMemcpyAsync(d_xlen, xlen.data(), nx * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        RL_HIP(hipMemcpyAsync(d_xchain, xchain.data(), xchain.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        RL_HIP(hipMemcpyAsync(a.an, an.data(), nA * sizeof(TieNode), hipMemcpyHostToDevice, s));
-        RL_HIP(hipMemcpyAsync(d_u0, u0.data(), nA * sizeof(long long), hipMemcpyHostToDevice, s));
-        if (!preds.empty()) RL_HIP(hipMemcpyAsync(d_preds, preds.data(), preds.size() * sizeof(TiePred), hipMemcpyHostToDevice, s));
         RL_HIP(hipMemsetAsync(a.need, 0, (size_t)nA * c.F * sizeof(int32_t), s));
         a.xnode = d_xnode; a.xlen = d_xlen; a.xchain = d_xchain; a.preds = d_preds;
         hipLaunchKernelGGL(k_tie_cand, dim3(c.F, nx), dim3(kFinThreads), 0, s, c, a);
@@ -559,7 +561,7 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds)
                 pairs.push_back(P);
             }
     const int npairs = (int)pairs.size();
-    bool walk = getenv("RLHIP_TIE_WALK") != nullptr || npairs == 0;
+    bool walk = getenv("RLHIP_TIE_WALK") != nullptr || npairs == 0 || (size_t)kTsWaves * c.TS * 4 > (size_t)60 * 1024;      // (huge threshold tables: the sort's cursors would not fit the LDS)
     std::vector<int32_t> cnts((size_t)npairs * c.TS);
     if (!walk) {       // cumulative bin counts of the pairs (exact): where every bin's run starts in the sorted values
         for (int p = 0; p < npairs; p++)
@@ -567,18 +569,18 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds)
                                   hipMemcpyDeviceToHost, s));
         RL_HIP(hipStreamSynchronize(s));
     }
-    std::vector<TieChain> chs; std::vector<int32_t> seg_chain;
+    std::vector<TieChain> chs; std::vector<int32_t> win_chain, chunk_chain;
     auto add_chain = [&](long long off, int len, int out) {
-        TieChain C; C.off = off; C.len = len; C.out = out; C.seg0 = (int32_t)seg_chain.size();
-        C.seglen = std::min(16384, std::max(2048, ((len / 256 + 2047) / 2048) * 2048));
-        const int ns = (len + C.seglen - 1) / C.seglen;
-        for (int j = 0; j < ns; j++) seg_chain.push_back((int32_t)chs.size());
+        TieChain C; C.off = off; C.len = len; C.out = out; C.win0 = (int32_t)win_chain.size();
+        C.win = std::min(16384, std::max(2048, ((len / 256 + 2047) / 2048) * 2048));
+        const int nw = (len + C.win - 1) / C.win;
+        for (int j = 0; j < nw; j++) win_chain.push_back((int32_t)chs.size());
+        for (int j = 0; j <= nw; j++) chunk_chain.push_back((int32_t)chs.size());       // chunk ids: win0 + chain index + local chunk
         chs.push_back(C);
     };
-    std::vector<int32_t> h_nthr;
+    std::vector<int32_t> &h_nthr = t->h_nthr;
     if (!walk) {
-        h_nthr.resize(c.F);
-        RL_HIP(hipMemcpy(h_nthr.data(), c.nthr, c.F * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if ((int)h_nthr.size() != c.F) { h_nthr.resize(c.F); RL_HIP(hipMemcpy(h_nthr.data(), c.nthr, c.F * sizeof(int32_t), hipMemcpyDeviceToHost)); }
         for (int i = 0; i < nA; i++) add_chain(u0[i], an[i].count, -(i + 1));
         for (int p = 0; p < npairs; p++) {
             const int32_t *cc = cnts.data() + (size_t)p * c.TS;
@@ -588,9 +590,9 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds)
             }
         }
     }
-    const int nch = (int)chs.size(), nseg = (int)seg_chain.size();
-    const size_t spec_bytes = v_total * 8 + (size_t)npairs * tiles_max * c.TS * 4 + (size_t)nseg * (16 + 16 + 8 + 8 * kSpW) + (size_t)nch * (16 + 8 + 8 + sizeof(TieChain)) +
-                              (size_t)npairs * sizeof(TiePair) + (size_t)nseg * 4 + 64 * 256;
+    const int nch = (int)chs.size(), nwin = (int)win_chain.size(), nchunks = (int)chunk_chain.size();
+    const size_t spec_bytes = v_total * 8 + (size_t)npairs * tiles_max * c.TS * 4 + (size_t)nwin * (16 + 16 + 4) + (size_t)nchunks * (4 + 16 + 8 + 8 * kSpW + 4) +
+                              (size_t)nch * (16 + 8 + 8 + sizeof(TieChain)) + (size_t)npairs * sizeof(TiePair) + (size_t)(nwin + nchunks) * 4 + 64 * 256;
     if (!walk && fixed_bytes + spec_bytes + ((size_t)1 << 20) > t->tie_cap) {
         // the arena has to grow: it moves, so stage 1 runs again in the new one (and later calls ask for this much up front)
         t->tie_hint = fixed_bytes + spec_bytes + ((size_t)1 << 20);
@@ -605,30 +607,34 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds)
         hipLaunchKernelGGL(k_tie_jsum, dim3(c.F, nbg + 1, nA), dim3(64), 0, s, c, a, nbg);
     } else {
         SpArgs sp; memset(&sp, 0, sizeof(sp));
-        sp.nchains = nch; sp.nseg = nseg; sp.npairs = npairs; sp.tiles_max = tiles_max;
-        TiePair *d_pairs = ar.take<TiePair>(npairs); TieChain *d_chs = ar.take<TieChain>(nch); int32_t *d_segc = ar.take<int32_t>(nseg + 1);
+        sp.nchains = nch; sp.nwin = nwin; sp.nchunks = nchunks; sp.npairs = npairs; sp.tiles_max = tiles_max;
+        std::vector<char> &blob = t->tie_blob; blob.clear();
+        auto put = [&](const void *src, size_t bytes) { const size_t o = (blob.size() + 15) & ~(size_t)15; blob.resize(o + bytes); if (bytes) memcpy(blob.data() + o, src, bytes); return o; };
+        const size_t o_pairs = put(pairs.data(), npairs * sizeof(TiePair)), o_chs = put(chs.data(), nch * sizeof(TieChain));
+        const size_t o_winc = put(win_chain.data(), nwin * sizeof(int32_t)), o_chunkc = put(chunk_chain.data(), nchunks * sizeof(int32_t));
+        char *d_blob = ar.take<char>(blob.size() + 16);
+        RL_HIP(hipMemcpyAsync(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, s));
+        TiePair *d_pairs = (TiePair *)(d_blob + o_pairs); TieChain *d_chs = (TieChain *)(d_blob + o_chs);
+        int32_t *d_winc = (int32_t *)(d_blob + o_winc), *d_chunkc = (int32_t *)(d_blob + o_chunkc);
         sp.vals = ar.take<double>(v_total + 1); sp.tbin = ar.take<int32_t>((size_t)npairs * tiles_max * c.TS);
-        sp.segsum = ar.take<double2>(nseg + 1); sp.segpre = ar.take<double2>(nseg + 1);
-        sp.centre = ar.take<unsigned long long>(nseg + 1); sp.table = ar.take<unsigned long long>((size_t)nseg * kSpW + 1);
-        sp.cstate = ar.take<int32_t>((size_t)nch * 4); sp.ckey = ar.take<unsigned long long>(nch); sp.cshift = ar.take<long long>(nch);
+        sp.wsum = ar.take<double2>(nwin + 1); sp.wpre = ar.take<double2>(nwin + 1);
+        sp.cstart = ar.take<int32_t>(nchunks + 1); sp.cpre = ar.take<double2>(nchunks + 1);
+        sp.centre = ar.take<unsigned long long>(nchunks + 1); sp.table = ar.take<unsigned long long>((size_t)nchunks * kSpW + 1);
+        sp.cstate = ar.take<int32_t>((size_t)nch * 4); sp.ckey = ar.take<unsigned long long>(nch); sp.cshift = ar.take<double>(nch);
         sp.open = ar.take<int32_t>(4);
         if (ar.used > t->tie_cap) return fail(RL_ERR_HIP, "tie-break: scratch arena too small (internal error)");
-        RL_HIP(hipMemcpyAsync(d_pairs, pairs.data(), npairs * sizeof(TiePair), hipMemcpyHostToDevice, s));
-        RL_HIP(hipMemcpyAsync(d_chs, chs.data(), nch * sizeof(TieChain), hipMemcpyHostToDevice, s));
-        RL_HIP(hipMemcpyAsync(d_segc, seg_chain.data(), nseg * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        sp.pairs = d_pairs; sp.chains = d_chs; sp.seg_chain = d_segc; sp.u0 = d_u0;
+        sp.pairs = d_pairs; sp.chains = d_chs; sp.win_chain = d_winc; sp.chunk_chain = d_chunkc; sp.u0 = d_u0;
         hipLaunchKernelGGL(k_tie_gather, dim3(std::min(4096, (maxcnt + kThreads - 1) / kThreads), nA), dim3(kThreads), 0, s, c, a, sp);
-        hipLaunchKernelGGL(k_ts_count, dim3(tiles_max, npairs), dim3(64), (size_t)c.TS * 4, s, c, a, sp);
+        hipLaunchKernelGGL(k_ts_count, dim3(tiles_max, npairs), dim3(kThreads), (size_t)c.TS * 4, s, c, a, sp);
         hipLaunchKernelGGL(k_ts_scan, dim3(npairs, nbg), dim3(64), 0, s, c, a, sp);
-        hipLaunchKernelGGL(k_ts_scatter, dim3(tiles_max, npairs), dim3(64), (size_t)c.TS * 4, s, c, a, sp);
+        hipLaunchKernelGGL(k_ts_scatter, dim3(tiles_max, npairs), dim3(kTsWaves * 64), (size_t)kTsWaves * c.TS * 4, s, c, a, sp);
         const int cb = (nch + kThreads - 1) / kThreads;
-        if (nseg > 0) hipLaunchKernelGGL(k_sp_sum, dim3(nseg), dim3(64), 0, s, sp);
+        if (nwin > 0) hipLaunchKernelGGL(k_sp_sum, dim3(nwin), dim3(64), 0, s, sp);
         hipLaunchKernelGGL(k_sp_scan, dim3(cb), dim3(kThreads), 0, s, sp);
-        if (nseg > 0) {
-            hipLaunchKernelGGL(k_sp_run<false>, dim3(nseg), dim3(64), 0, s, sp);
-            hipLaunchKernelGGL(k_sp_drift, dim3(cb), dim3(kThreads), 0, s, sp);
-            hipLaunchKernelGGL(k_sp_run<false>, dim3(nseg), dim3(64), 0, s, sp);
-        }
+        if (nwin > 0) hipLaunchKernelGGL(k_sp_bounds, dim3(nwin), dim3(64), 0, s, sp);
+        hipLaunchKernelGGL(k_sp_run<false>, dim3(nchunks), dim3(kSpW), 0, s, sp);
+        hipLaunchKernelGGL(k_sp_drift, dim3(cb), dim3(kThreads), 0, s, sp);
+        hipLaunchKernelGGL(k_sp_run<false>, dim3(nchunks), dim3(kSpW), 0, s, sp);
         int32_t open = 0;
         for (int rep = 0; rep <= kSpRepairs; rep++) {
             RL_HIP(hipMemsetAsync(sp.open, 0, sizeof(int32_t), s));
@@ -637,15 +643,18 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds)
             RL_HIP(hipStreamSynchronize(s));
             if (open == 0) break;
             t->tie_spec_repairs++;
-            hipLaunchKernelGGL(k_sp_run<true>, dim3(nseg), dim3(64), 0, s, sp);
+            hipLaunchKernelGGL(k_sp_run<true>, dim3(nchunks), dim3(kSpW), 0, s, sp);
         }
-        std::vector<int32_t> cst((size_t)nch * 4);
-        RL_HIP(hipMemcpyAsync(cst.data(), sp.cstate, cst.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        RL_HIP(hipStreamSynchronize(s));
-        for (int i = 0; i < nch; i++) { t->tie_spec_miss += cst[4 * (size_t)i + 1]; t->tie_spec_serial += cst[4 * (size_t)i + 2]; }
-        t->tie_spec_segs += nseg;
+        if (c.steplog) {       // debug statistics (RLHIP_STEPLOG): window misses / serial chunks of this resolution
+            std::vector<int32_t> cst((size_t)nch * 4);
+            RL_HIP(hipMemcpyAsync(cst.data(), sp.cstate, cst.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            RL_HIP(hipStreamSynchronize(s));
+            for (int i = 0; i < nch; i++) { t->tie_spec_miss += cst[4 * (size_t)i + 1]; t->tie_spec_serial += cst[4 * (size_t)i + 2]; }
+        }
+        t->tie_spec_segs += nchunks;
     }
-    hipLaunchKernelGGL(k_tie_finish, dim3(1), dim3(kFinThreads), fin_lds, s, c, a, nodes_in_lds);
+    const size_t tf_lds = std::max(fin_lds, std::min((size_t)96 * 1024, (size_t)chain_cap * c.TS * 8));       // staging of a feature's chain arrays; select_step afterwards
+    hipLaunchKernelGGL(k_tie_finish, dim3(1), dim3(kFinThreads), tf_lds, s, c, a, nodes_in_lds, (int)tf_lds);
     RL_HIP(hipGetLastError());
     RL_HIP(hipStreamSynchronize(s));
     t->tie_stalls++; t->tie_nodes += nx; t->tie_chain_nodes += nA;
@@ -1146,6 +1155,7 @@ int rl_create(const rl_params *p, rl_trainer **out)
     RL_HIP(hipFuncSetAttribute((const void *)k_lambda_fused<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaFusedMaxK * (256 + 8) * 16 + 8192));
     RL_HIP(hipFuncSetAttribute((const void *)k_lambda_fused<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaFusedMaxK * (256 + 8) * 16 + 8192));
     RL_HIP(hipFuncSetAttribute((const void *)k_chain_stitch, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RL_HIP(hipFuncSetAttribute((const void *)k_tie_finish, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     *out = t.release();
     return RL_OK;
 }
@@ -2084,6 +2094,7 @@ int rl_debug_float_chain(int32_t device, const double *x, int64_t n, const int64
     t->p.device = device;
     RL_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
     RL_HIP(hipFuncSetAttribute((const void *)k_chain_stitch, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RL_HIP(hipFuncSetAttribute((const void *)k_tie_finish, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     struct Guard { rl_trainer *t; ~Guard() { (void)hipStreamSynchronize(t->stream); (void)hipStreamDestroy(t->stream); for (void *q : t->pinned) (void)hipHostFree(q); } } guard{t.get()};
     ChainBufs b;
     int rc = alloc_chain(t.get(), b, n_seg, 1, n, true);
