@@ -149,6 +149,8 @@ for case in range(n_cases):
         Xv = rng.random((int(vqoff[-1]), F)).astype(np.float32)
         Xv[:, ::3] = np.floor(Xv[:, ::3] * 7)
         labv = np.floor(rng.random(int(vqoff[-1])) * 5).astype(np.float32)
+    if os.environ.get("FUZZ_ONLY") and str(case) not in os.environ["FUZZ_ONLY"].split(","):
+        continue                                   # (the random stream has been drawn: the listed cases see the data they saw in the full run)
     desc = dict(case=case, n=n, F=F, kind=str(kind), ranker=str(ranker), metric=str(metric), k=k, leaves=leaves, mls=mls, tc=tc, frate=frate, lr=lr, rounds=rounds, valid=with_valid, estop=estop)
     try:
         o = O.Oracle(X, lab, qoff, n_trees=rounds, n_leaves=leaves, lr=lr, n_threshold=tc, mls=mls, k=k, ranker=str(ranker), metric=str(metric),
@@ -177,6 +179,17 @@ for case in range(n_cases):
                 nt = assert_equivalent(to, tg, X, ctx="round %d" % m)
                 if frate >= 1.0 and not os.environ.get("FUZZ_DIST"):
                     other_splits += nt; compared_splits += int((to.trimmed()["feature"] != -1).sum())
+                    if nt and os.environ.get("FUZZ_VERBOSE"):
+                        print("  case %d round %d: %d split(s) store another (feature, threshold) %s" % (case, m, nt, desc), flush=True)
+                        a_, b_ = to.trimmed(), tg.trimmed()
+                        for i_ in range(len(a_["feature"])):
+                            if a_["feature"][i_] != b_["feature"][i_] or a_["threshold"][i_] != b_["threshold"][i_]:
+                                print("    node %d (count %d): oracle (f %d, %r) gpu (f %d, %r)" % (i_, a_["count"][i_], a_["feature"][i_], float(a_["threshold"][i_]), b_["feature"][i_], float(b_["threshold"][i_])), flush=True)
+                                if os.environ.get("FUZZ_ONLY"):
+                                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                                    from tie_diag import java_restatement
+                                    java_restatement(a_, node_members(a_, X), i_, lam, g.array("BINS"), g.array("NBINS"), g.array("THRESHOLDS"), mls)
+                        print("    TIE_STATS", g.array("TIE_STATS").tolist(), flush=True)
                 if JAVA:
                     assert nt == 0, "RL_FLAG_JAVA_ORDER: %d splits store another (feature, threshold) than the oracle's, round %d" % (nt, m)
             except AssertionError:

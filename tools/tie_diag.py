@@ -66,9 +66,11 @@ def java_restatement(tree, members, x, lam, bins, nbins, thr, mls):
 
 def main():
     n_docs, n_feat, kind, leaves, mls, rounds, seed = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
+    tc = int(sys.argv[8]) if len(sys.argv) > 8 else 256
+    ranker = sys.argv[9] if len(sys.argv) > 9 else "LAMBDAMART"
     X, lab, qoff = synth.make_dataset(n_docs, n_feat, kind, seed_offset=seed)
-    o = O.Oracle(X, lab, qoff, n_trees=rounds, n_leaves=leaves, mls=mls)
-    g = N.Trainer(n_trees=rounds, n_leaves=leaves, min_leaf_support=mls)
+    o = O.Oracle(X, lab, qoff, n_trees=rounds, n_leaves=leaves, mls=mls, n_threshold=tc, ranker=ranker)
+    g = N.Trainer(n_trees=rounds, n_leaves=leaves, min_leaf_support=mls, n_threshold=tc, ranker=ranker)
     g.set_train(X, lab, qoff)
     o.init(); g.init()
     bins, nbins, thr = g.array("BINS"), g.array("NBINS"), g.array("THRESHOLDS")
