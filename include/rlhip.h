@@ -67,6 +67,9 @@ enum {                                  /* rl_params.flags */
     RL_FLAG_TIMING_NODES = 8,           /* ... and around every growth step's node-histogram launch (30 event pairs per round) */
     RL_FLAG_SERIAL_CHAIN = 4,           /* evaluate the float running sums with the literal serial kernel instead of
                                            the exact parallel scheme (same results; for cross-checks) */
+    RL_FLAG_FIRST_TIE = 32,             /* exact ties between split candidates keep the first one in scan order instead of being re-decided in the Java's
+                                           summation order (the lazy tie-break; default on one GPU without feature sampling).  This is what
+                                           sharded runs do anyway: a one-GPU run with the flag equals a sharded run bit for bit. */
     RL_FLAG_JAVA_ORDER = 16             /* strict mode: split gains and node deviances come from the f64 histogram RankLib itself
                                            would hold -- every (feature, bin) sum accumulated sequentially in ascending sample
                                            order (FeatureHistogram.java:126-146,166-195), sequential prefix, right sibling =

@@ -35,7 +35,7 @@ class RlTree(C.Structure):
                 ("deviance", C.POINTER(C.c_double)), ("count", C.POINTER(C.c_int32))]
 
 
-RL_FLAG_TIMING, RL_FLAG_SERIAL_CHAIN, RL_FLAG_TIMING_NODES, RL_FLAG_JAVA_ORDER = 2, 4, 8, 16
+RL_FLAG_TIMING, RL_FLAG_SERIAL_CHAIN, RL_FLAG_TIMING_NODES, RL_FLAG_JAVA_ORDER, RL_FLAG_FIRST_TIE = 2, 4, 8, 16, 32
 ARR = dict(LAMBDA=1, WEIGHT=2, SCORE=3, VALID_SCORE=4, NBINS=5, THRESHOLDS=6, BINS=7, ROOT_COUNT=8, ROOT_SUM=9,
            QUANT=10, ROOT_SUM_FIXED=11, NDCG_PER_QUERY=12, CHAIN_STATS=13, CHAIN_MISS=14, GROW_STATS=15, PHASE_CLOCKS=16,
            ROOT_SUM_JAVA=17, GROW_DOCS=18, SPARSE_INFO=19, STEP_LOG=20, TIE_STATS=21)

@@ -1109,7 +1109,7 @@ int rl_create(const rl_params *p, rl_trainer **out)
     if (p->min_leaf_support < 1) return fail(RL_ERR_INVALID, "min_leaf_support must be >= 1");
     if (p->n_threshold != -1 && (p->n_threshold < 1 || p->n_threshold + 1 > kMaxBins))
         return fail(RL_ERR_UNSUPPORTED, "n_threshold must be -1 or in [1," + std::to_string(kMaxBins - 1) + "]");
-    if (p->flags & ~(RL_FLAG_TIMING | RL_FLAG_TIMING_NODES | RL_FLAG_SERIAL_CHAIN | RL_FLAG_JAVA_ORDER)) return fail(RL_ERR_INVALID, "unknown bit in rl_params.flags");
+    if (p->flags & ~(RL_FLAG_TIMING | RL_FLAG_TIMING_NODES | RL_FLAG_SERIAL_CHAIN | RL_FLAG_JAVA_ORDER | RL_FLAG_FIRST_TIE)) return fail(RL_ERR_INVALID, "unknown bit in rl_params.flags");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(RL_ERR_NO_DEVICE, "no HIP device visible: librlhip has no CPU fallback");
@@ -1274,7 +1274,7 @@ int rl_init(rl_trainer *t)
     // lazy Java-order tie-break (rl_tie.inc): the default path's exact ties resolved as the Java's summation order resolves them.  Not with
     // feature sampling (the Java's draw is unseeded: nothing to match), not sharded (the Java's order is ONE sequence over all documents), not in
     // the strict mode (every candidate already comes from the Java-order histogram)
-    c.tie_on = (c.fs_size == F && !t->dist && !(t->p.flags & RL_FLAG_JAVA_ORDER) && !getenv("RLHIP_TIE_OFF")) ? 1 : 0;
+    c.tie_on = (c.fs_size == F && !t->dist && !(t->p.flags & (RL_FLAG_JAVA_ORDER | RL_FLAG_FIRST_TIE)) && !getenv("RLHIP_TIE_OFF")) ? 1 : 0;
     // rows of a ranked list whose pairs the lambda loop visits (LambdaMART.java:375-377: j <= cutoff or k <= cutoff); for
     // NDCG / DCG / ERR row `cutoff` itself only holds zero swap changes
     c.k = (t->p.metric == RL_METRIC_MAP) ? t->p.metric_k + 1 : t->p.metric_k;

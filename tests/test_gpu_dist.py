@@ -22,8 +22,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def single(n_docs, n_feat, kind, seed, leaves, rounds, dist_mode=None, ranker="LAMBDAMART", metric="NDCG", k=10, opts=()):
     X, lab, qoff = synth.make_dataset(n_docs, n_feat, kind, seed_offset=seed)
+    # RL_FLAG_FIRST_TIE: sharded runs keep the first of exactly tied candidates (the Java's summation order is one sequence over all documents);
+    # with the flag a one-GPU run does the same, and the two must agree bit for bit
     g = N.Trainer(n_trees=rounds, n_leaves=-1 if "leafm1" in opts else leaves, ranker=ranker, metric=metric, metric_k=k,
-                  min_leaf_support=40 if "leafm1" in opts else 1)
+                  min_leaf_support=40 if "leafm1" in opts else 1, flags=N.RL_FLAG_FIRST_TIE)
     g.set_train(X, lab, qoff)
     if "qrel" in opts:       # as tests/dist_worker.py
         qi = np.arange(len(qoff) - 1)
@@ -160,7 +162,7 @@ def test_validation_set_under_sharding(world, tmp_path):
     X, lab, qoff = synth.make_dataset(cfg[0], cfg[1], cfg[2], seed_offset=cfg[3])
     Xv, lv, qv = synth.make_dataset(cfg[0] // 3, cfg[1], cfg[2], seed_offset=cfg[3] + 77)
     lv = lv[::-1].copy()                      # as tests/dist_worker.py does
-    g = N.Trainer(n_trees=cfg[5], n_leaves=cfg[4], early_stop_rounds=1)
+    g = N.Trainer(n_trees=cfg[5], n_leaves=cfg[4], early_stop_rounds=1, flags=N.RL_FLAG_FIRST_TIE)
     g.set_train(X, lab, qoff); g.set_validation(Xv, lv, qv); g.init()
     mets, vmets = [], []
     for _ in range(cfg[5]):
