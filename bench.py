@@ -450,6 +450,33 @@ def main():
     if sustained is not None:
         out["config"]["sustained_rounds_per_s"] = sustained
         out["config"]["sustained_over_rounds"] = args.sustain
+    ts = g.array("TIE_STATS")
+    out["config"]["tie_break"] = {
+        "mode": "lazy Java-order (exact ties re-decided in the reference's summation order, DESIGN.md 4.13)" if (world == 1 and not args.java_order) else
+                ("strict: every candidate from the Java-order histogram" if args.java_order else "first candidate in scan order (sharded run)"),
+        "resolutions": int(ts[0]), "nodes": int(ts[1]), "chain_documents": int(ts[3]), "host_ms": float(ts[4]) / 1e3,
+        "note": "whole run of this trainer (warm-up, timed, sustained and per-step-timing rounds)"}
+    if "roofline" in out and "node_histograms" in out["roofline"]:
+        # the kernel with the largest share of a round is the child-node histogram, not the root pass `frac` is quoted on
+        out["roofline"]["frac_time_dominant"] = out["roofline"]["node_histograms"]["frac"]
+        out["roofline"]["time_dominant_kernel"] = "rl::k_hist<false,16> (node_histograms)"
+    if world == 1 and args.c1_trees > 0 and not args.java_order:
+        # BASELINE.json configs[1] as stated: MSLR-WEB10K shape, 1000 trees, 31 leaves, one GPU -- the whole run, not a window of it
+        n1, f1, k1, _, l1 = synth.SHAPES["c1"]
+        X1, lab1, qoff1, q1 = synth.make_shard(n1, f1, k1, 0, 1)
+        g1 = N.Trainer(n_trees=args.c1_trees, n_leaves=l1, device=local_rank)
+        g1.set_train(X1, lab1, qoff1)
+        g1.init()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        g1.boost_rounds_async(args.c1_trees)
+        g1.sync()
+        dt1 = time.perf_counter() - t1
+        ts1 = g1.array("TIE_STATS")
+        out["config"]["c1_full_run"] = {"workload": "configs[1]: %d docs x %d features, %d queries, %d trees x %d leaves, one GPU" % (n1, f1, q1, args.c1_trees, l1),
+                                        "rounds_per_s": args.c1_trees / dt1, "seconds": dt1, "ndcg10_train": float(g1.round_metrics(args.c1_trees - 1)[0]),
+                                        "tie_resolutions": int(ts1[0]), "tie_host_ms": float(ts1[4]) / 1e3}
+        del g1
 
     if args.cpu_rounds > 0 and world == 1:
         import oracle_ffi as O

@@ -118,6 +118,12 @@ struct Ctx {
     const uint16_t *dbins;  // [Npad][numFG][kHistFG]  document-major: ALL groups of a document adjacent (numFG x 32 bytes).  A sparse node's
                             // sample list touches one 128-byte memory line per (document, group) in gbins -- 4 x the bytes it uses -- but only
                             // the document's own ~numFG/4 lines here; the feature-group blocks of one chunk run on one XCD and share them in L2
+    // packed rows (rl_kernels_round.inc pbin8_of; only when the threshold tables have at most 257 entries): one byte per bin + a 16-bit mask per
+    // (document, group) for bin 256
+    int32_t p8, pd_stride;          // 0 = off, 1 = root pass, 2 = child passes too; bytes per document row of pdbins (16 numFG low bytes, then 2 numFG mask bytes, padded to 64)
+    const unsigned char *pbins;     // [numFG][Npad][16]  group-major low bytes (root pass)
+    const uint16_t *phib;           // [numFG][Npad]      group-major masks
+    const unsigned char *pdbins;    // [Npad][pd_stride]  document-major rows (child passes)
     int32_t dm_gstride;        // groups per document row of dbins: numFG rounded up to a multiple of 4 (rows start on 128-byte lines)
     int32_t dm_root, dm_div;   // document-major rows for the root pass (0 / 1); for a node of cnt samples when cnt * dm_div <= N (0 = never, 1 = every child)
     int32_t sub;            // features of a group handled per histogram block (kHistFG unless the threshold table is huge)

@@ -408,7 +408,12 @@ static void launch_hist(const Ctx &c, int gx, int gy, size_t lds, hipStream_t s)
 {
     const dim3 g(gx, (gy + 7) & ~7), b(kThreads);      // the XCD-aware block map of k_hist wants a multiple of 8 chunks (the extra blocks exit)
     if (c.sub == 16 && c.TS <= kHistLdsStride) {
-        if (c.any_runs) hipLaunchKernelGGL((k_hist<ROOT, 16, kHistLdsStride, true>), g, b, lds, s, c);
+        // packed rows for the root pass only (measured at c2: 43 % fewer bytes buy the root pass 9 % -- it is bound by LDS atomics, not by HBM --
+        // and the child passes nothing: their extra bit-field work costs what the two 128-byte lines per document instead of three save)
+        if (c.p8 && (ROOT || c.p8 > 1)) {
+            if (c.any_runs) hipLaunchKernelGGL((k_hist<ROOT, 16, kHistLdsStride, true, true>), g, b, lds, s, c);
+            else hipLaunchKernelGGL((k_hist<ROOT, 16, kHistLdsStride, false, true>), g, b, lds, s, c);
+        } else if (c.any_runs) hipLaunchKernelGGL((k_hist<ROOT, 16, kHistLdsStride, true>), g, b, lds, s, c);
         else hipLaunchKernelGGL((k_hist<ROOT, 16, kHistLdsStride>), g, b, lds, s, c);
         return;
     }
@@ -1131,6 +1136,10 @@ int rl_create(const rl_params *p, rl_trainer **out)
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 16, kHistLdsStride>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 16, kHistLdsStride, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 16, kHistLdsStride, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 16, kHistLdsStride, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 16, kHistLdsStride, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 16, kHistLdsStride, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 16, kHistLdsStride, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
@@ -1396,6 +1405,20 @@ int rl_init(rl_trainer *t)
         RL_HIP(hipMemsetAsync(d_dbins, 0, (size_t)c.dm_gstride * Npad * kHistFG * sizeof(uint16_t), s));
         hipLaunchKernelGGL(k_docmajor, dim3(4096), dim3(kThreads), 0, s, (const uint16_t *)d_gbins, d_dbins, Npad, c.numFG, c.dm_gstride);
         c.dbins = d_dbins;
+        // packed rows: one byte per bin + a mask for bin 256 (possible when no table has more than 257 entries; RLHIP_P8=0 keeps the 16-bit rows)
+        c.p8 = 0;
+        const int p8_mode = getenv("RLHIP_P8") ? atoi(getenv("RLHIP_P8")) : 1;        // 0 = 16-bit rows everywhere, 1 = packed rows for the root pass (default), 2 = also for child passes
+        if (TS <= 257 && c.sub == 16 && p8_mode > 0) {
+            unsigned char *d_pb = nullptr, *d_pd = nullptr; uint16_t *d_ph = nullptr;
+            c.pd_stride = (c.numFG * 18 + 63) & ~63;
+            RL_HIP(t->pool.alloc(&d_pb, (size_t)c.numFG * Npad * 16)); RL_HIP(t->pool.alloc(&d_ph, (size_t)c.numFG * Npad));
+            if (p8_mode > 1) {
+                RL_HIP(t->pool.alloc(&d_pd, (size_t)Npad * c.pd_stride));
+                RL_HIP(hipMemsetAsync(d_pd, 0, (size_t)Npad * c.pd_stride, s));
+            }
+            hipLaunchKernelGGL(k_pack_rows, dim3(4096), dim3(kThreads), 0, s, (const uint16_t *)d_gbins, d_pb, d_ph, d_pd, Npad, c.numFG, c.pd_stride);
+            c.pbins = d_pb; c.phib = d_ph; c.pdbins = d_pd; c.p8 = p8_mode > 1 ? 2 : 1;
+        }
         c.dm_root = 0; c.dm_div = 1;      // measured at c2 (profiles/r02d_dm_sweep.txt): every child pass gains, the root pass loses
         if (const char *e = getenv("RLHIP_DM_ROOT")) c.dm_root = atoi(e) ? 1 : 0;      // tuning knobs (tools/), not API
         if (const char *e = getenv("RLHIP_DM_DIV")) c.dm_div = std::max(0, atoi(e));
