@@ -99,6 +99,7 @@ struct rl_trainer {
     long long tie_stalls = 0, tie_nodes = 0, tie_chain_nodes = 0, tie_chain_docs = 0;      // lazy tie-break (rl_tie.inc): resolutions run, nodes resolved, chain nodes / documents summed
     long long tie_us = 0, tie_spec_segs = 0, tie_spec_miss = 0, tie_spec_serial = 0, tie_spec_repairs = 0;      // host time in resolve_ties; segments evaluated, window misses, serial segments, repair passes
     std::vector<int32_t> h_nthr; std::vector<char> tie_blob;
+    void *tie_pin = nullptr; size_t tie_pin_cap = 0;                                          // pinned staging of its small device-to-host reads
     void *tie_buf = nullptr; size_t tie_cap = 0, tie_hint = 0;                                              // scratch arena of resolve_ties (only ever grows)
     int32_t n_kept = 0;         // trees kept after rollback (== round until rl_finish)
     int32_t best_round = 2147483647 - 2;     // LambdaMART.bestModelOnValidation  LambdaMART.java:50
@@ -463,11 +464,23 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds)
     Ctx &c = t->ctx;
     hipStream_t s = t->stream;
     const auto t_begin = std::chrono::steady_clock::now();
+    // small reads come back through one pinned buffer (a pageable copy costs tens of microseconds each)
+    const size_t pin_need = sizeof(TreeState) + (size_t)(c.NC + 2) * sizeof(NodeRec) + (size_t)kTieMaxChain * c.F * 4 + ((size_t)1 << 20);
+    if (t->tie_pin_cap < pin_need) {
+        if (t->tie_pin) (void)hipHostFree(t->tie_pin);
+        t->tie_pin = nullptr; t->tie_pin_cap = 0;
+        if (hipHostMalloc(&t->tie_pin, pin_need, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return fail(RL_ERR_HIP, "tie-break: no pinned host memory"); }
+        t->tie_pin_cap = pin_need;
+    }
+    char *pin = (char *)t->tie_pin;
+    RL_HIP(hipMemcpyAsync(pin, c.st, sizeof(TreeState), hipMemcpyDeviceToHost, s));
+    RL_HIP(hipMemcpyAsync(pin + sizeof(TreeState), c.nodes, (size_t)c.NC * sizeof(NodeRec), hipMemcpyDeviceToHost, s));
+    RL_HIP(hipStreamSynchronize(s));
     TreeState st;
-    RL_HIP(hipMemcpy(&st, c.st, sizeof(st), hipMemcpyDeviceToHost));
+    memcpy(&st, pin, sizeof(st));
     if (st.stall_n <= 0 || st.stall_n > kSpec) return fail(RL_ERR_STATE, "resolve_ties without a stalled tree (internal error)");
     std::vector<NodeRec> nodes((size_t)st.n_nodes);
-    RL_HIP(hipMemcpy(nodes.data(), c.nodes, nodes.size() * sizeof(NodeRec), hipMemcpyDeviceToHost));
+    memcpy(nodes.data(), pin + sizeof(TreeState), nodes.size() * sizeof(NodeRec));
     std::vector<TieNode> an; std::vector<TiePred> preds; std::map<int, int> a_of;
     auto is_right = [&](int x) { return nodes[x].parent >= 0 && nodes[nodes[x].parent].pr == x; };
     auto direct = [&](int x) -> int {        // chain node of a directly accumulated node, with the split predicates of its path from the root
@@ -549,8 +562,9 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds)
             hipLaunchKernelGGL(k_tie_scan, dim3(nA), dim3(kThreads), 0, s, a, tiles);
             hipLaunchKernelGGL(k_tie_scatter, dim3(tiles, nA), dim3(kThreads), 0, s, c, a, tiles);
         }
-        RL_HIP(hipMemcpyAsync(need.data(), a.need, need.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        RL_HIP(hipMemcpyAsync(pin, a.need, need.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         RL_HIP(hipStreamSynchronize(s));
+        memcpy(need.data(), pin, need.size() * sizeof(int32_t));
         return RL_OK;
     };
     { int rc1 = stage1(); if (rc1) return rc1; }
@@ -569,10 +583,12 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds)
     bool walk = getenv("RLHIP_TIE_WALK") != nullptr || npairs == 0 || (size_t)kTsWaves * c.TS * 4 > (size_t)60 * 1024;      // (huge threshold tables: the sort's cursors would not fit the LDS)
     std::vector<int32_t> cnts((size_t)npairs * c.TS);
     if (!walk) {       // cumulative bin counts of the pairs (exact): where every bin's run starts in the sorted values
+        if (cnts.size() * sizeof(int32_t) > t->tie_pin_cap) return fail(RL_ERR_UNSUPPORTED, "tie-break: too many (chain node, feature) pairs");
         for (int p = 0; p < npairs; p++)
-            RL_HIP(hipMemcpyAsync(cnts.data() + (size_t)p * c.TS, c.cum_cnt + ((size_t)an[pairs[p].a].node * c.F + pairs[p].f) * c.TS, (size_t)c.TS * sizeof(int32_t),
+            RL_HIP(hipMemcpyAsync(pin + (size_t)p * c.TS * sizeof(int32_t), c.cum_cnt + ((size_t)an[pairs[p].a].node * c.F + pairs[p].f) * c.TS, (size_t)c.TS * sizeof(int32_t),
                                   hipMemcpyDeviceToHost, s));
         RL_HIP(hipStreamSynchronize(s));
+        memcpy(cnts.data(), pin, cnts.size() * sizeof(int32_t));
     }
     std::vector<TieChain> chs; std::vector<int32_t> win_chain, chunk_chain;
     auto add_chain = [&](long long off, int len, int out) {
@@ -644,8 +660,9 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds)
         for (int rep = 0; rep <= kSpRepairs; rep++) {
             RL_HIP(hipMemsetAsync(sp.open, 0, sizeof(int32_t), s));
             hipLaunchKernelGGL(k_sp_stitch, dim3(cb), dim3(kThreads), 0, s, sp, a, rep == kSpRepairs ? 1 : 0);
-            RL_HIP(hipMemcpyAsync(&open, sp.open, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            RL_HIP(hipMemcpyAsync(pin, sp.open, sizeof(int32_t), hipMemcpyDeviceToHost, s));
             RL_HIP(hipStreamSynchronize(s));
+            memcpy(&open, pin, sizeof(open));
             if (open == 0) break;
             t->tie_spec_repairs++;
             hipLaunchKernelGGL(k_sp_run<true>, dim3(nchunks), dim3(kSpW), 0, s, sp);
@@ -1183,6 +1200,7 @@ void rl_destroy(rl_trainer *t)
     if (t->stream) (void)hipStreamDestroy(t->stream);
     if (t->h_progress) (void)hipHostFree(t->h_progress);
     if (t->tie_buf) (void)hipFree(t->tie_buf);
+    if (t->tie_pin) (void)hipHostFree(t->tie_pin);
     for (void *q : t->pinned) (void)hipHostFree(q);
     delete t;
 }
