@@ -96,8 +96,7 @@ def bench_infer(args):
     world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("gloo")
+        dist = init_control_plane()
     torch.cuda.set_device(local_rank)
     F, L = 136, 31
     X, lab, qoff = synth.make_dataset(200000, F, "mslr")
@@ -199,6 +198,23 @@ def bench_infer(args):
     print(json.dumps(out))
 
 
+def init_control_plane():
+    """gloo process group for rendezvous, the unique-id broadcast and the timing max.  Gloo announces its connections on STDOUT ("[Gloo] Rank 0 is
+    connected to ..."), which would break the one-JSON-line contract: file descriptor 1 points at stderr while the group is set up."""
+    import torch.distributed as dist
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        dist.init_process_group("gloo")
+        dist.barrier()                       # (the full mesh is connected -- and announced -- no later than the first collective)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+    return dist
+
+
 def respawn(n):
     """`python bench.py --gpus N` as typed: re-exec this script as N ranks (one per GPU) under torch.distributed.run on a free local port.
     Rank 0 prints the one JSON line; stdout / stderr / exit code are the launcher's."""
@@ -264,8 +280,7 @@ def main():
     if world > 1:
         # control plane only (rendezvous, unique-id broadcast, timing max): gloo.  The data path (histogram
         # all-reduce, gathers) is the library's own RCCL communicator over xGMI.
-        import torch.distributed as dist
-        dist.init_process_group("gloo")
+        dist = init_control_plane()
 
     n_docs, n_feat, kind, n_trees, n_leaves = synth.SHAPES[args.shape]
     weak = args.scaling == "weak"

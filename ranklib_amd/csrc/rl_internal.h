@@ -86,7 +86,7 @@ struct TreeState {
     long long root_sq;                // sum over all docs of rint(lambda^2 * 2^E2)
     // lazy tie-break (rl_tie.inc): nodes select_step wanted to partition whose exactly tied best split the Java's rounding noise decides; while
     // stall_n > 0 the step has no slots (every growth kernel is a no-op) and the host runs the resolution kernels
-    int32_t stall_n, stall_node[kSpec], stall_pad[3 + (4 - kSpec % 4) % 4];
+    int32_t stall_n, stall_node[kSpec], defer_any, stall_pad[2 + (4 - kSpec % 4) % 4];      // defer_any: the tree holds nodes whose stored threshold awaits the batched tie-break
     SlotRec slot[kSpec];
     int32_t arrive1[kSpec][16];        // first-level arrival counters of k_hist_finish (<= 16 feature groups per slot)
 };
@@ -162,7 +162,7 @@ struct Ctx {
                                                                        // PREPARED node), partitioned (prepared nodes), left children of COMMITTED splits (what the
                                                                        // Java accumulates: rho of SURVEY.md 8d), committed split nodes (nu)
     float *round_metric;                                               // [n_trees][2]
-    // host-visible (pinned, fine-grained) growth progress: tree_seq << 32 | select_step calls in the tree << 1 | done.
+    // host-visible (pinned, fine-grained) growth progress: tree_seq << 32 | stalled << 31 | deferred ties << 30 | select_step calls in the tree << 1 | done.
     // A HINT only: the host uses it to stop enqueuing growth steps of a finished tree (extra steps are no-ops).
     unsigned long long *progress;
     // sparse-column path of the root pass (rl_csc.inc, BASELINE.json configs[3])

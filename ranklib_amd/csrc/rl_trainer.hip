@@ -97,6 +97,7 @@ struct rl_trainer {
     unsigned long long chain_seq = 0; std::vector<void *> pinned;     // chain pass tags; pinned words of the chains (freed in rl_destroy)
     int32_t synced_rounds = 0;
     long long tie_stalls = 0, tie_nodes = 0, tie_chain_nodes = 0, tie_chain_docs = 0;      // lazy tie-break (rl_tie.inc): resolutions run, nodes resolved, chain nodes / documents summed
+    long long tie_batches = 0;      // of the resolutions, the batched ones at the end of a tree (deferred plateau ties)
     long long tie_us = 0, tie_spec_segs = 0, tie_spec_miss = 0, tie_spec_serial = 0, tie_spec_repairs = 0;      // host time in resolve_ties; segments evaluated, window misses, serial segments, repair passes
     std::vector<int32_t> h_nthr; std::vector<char> tie_blob;
     void *tie_pin = nullptr; size_t tie_pin_cap = 0;                                          // pinned staging of its small device-to-host reads
@@ -459,7 +460,10 @@ static int tie_arena_reserve(rl_trainer *t, size_t bytes)
     return RL_OK;
 }
 
-static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds)
+// deferred = false: the tree is stalled on TreeState::stall_node (ties whose candidates may cut the node differently); afterwards the growth resumes.
+// deferred = true: the tree is grown; the committed nodes flagged 0x40 (plateau ties of right children: the partition was known, the stored
+// threshold was not) get the Java's threshold, all of them in one batch, before the tree is exported.
+static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool deferred = false)
 {
     Ctx &c = t->ctx;
     hipStream_t s = t->stream;
@@ -478,9 +482,13 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds)
     RL_HIP(hipStreamSynchronize(s));
     TreeState st;
     memcpy(&st, pin, sizeof(st));
-    if (st.stall_n <= 0 || st.stall_n > kSpec) return fail(RL_ERR_STATE, "resolve_ties without a stalled tree (internal error)");
+    if (!deferred && (st.stall_n <= 0 || st.stall_n > kSpec)) return fail(RL_ERR_STATE, "resolve_ties without a stalled tree (internal error)");
     std::vector<NodeRec> nodes((size_t)st.n_nodes);
     memcpy(nodes.data(), pin + sizeof(TreeState), nodes.size() * sizeof(NodeRec));
+    std::vector<int> todo;
+    if (deferred) { for (int x = 0; x < st.n_nodes; x++) if (nodes[x].left >= 0 && (nodes[x].tie & 0xc0) == 0x40) todo.push_back(x); }
+    else for (int x = 0; x < st.stall_n; x++) todo.push_back(st.stall_node[x]);
+    if (todo.empty()) return RL_OK;
     std::vector<TieNode> an; std::vector<TiePred> preds; std::map<int, int> a_of;
     auto is_right = [&](int x) { return nodes[x].parent >= 0 && nodes[nodes[x].parent].pr == x; };
     auto direct = [&](int x) -> int {        // chain node of a directly accumulated node, with the split predicates of its path from the root
@@ -496,13 +504,13 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds)
         a_of[x] = (int)an.size() - 1;
         return (int)an.size() - 1;
     };
-    const int nx = st.stall_n;
+    const int nx = (int)todo.size();
     std::vector<std::vector<int>> chains((size_t)nx);
     size_t chain_cap = 1;
     for (int x = 0; x < nx; x++) {
         // J(X): X itself when the Java accumulates it; else J(parent) - J(left sibling), the parent first (top-down)
         std::vector<int> subs;               // left siblings, bottom-up
-        int cur = st.stall_node[x];
+        int cur = todo[x];
         while (is_right(cur)) { subs.push_back(nodes[nodes[cur].parent].pl); cur = nodes[cur].parent; }
         chains[x].push_back(direct(cur));
         for (auto it = subs.rbegin(); it != subs.rend(); ++it) chains[x].push_back(direct(*it));
@@ -522,7 +530,7 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds)
     if (list_total > ((size_t)1 << 31) - 1) return fail(RL_ERR_UNSUPPORTED, "tie-break: member lists beyond 2^31 entries");
     std::vector<int32_t> xlen((size_t)nx), xchain((size_t)nx * chain_cap, 0), xnode((size_t)nx);
     for (int x = 0; x < nx; x++) {
-        xnode[x] = st.stall_node[x]; xlen[x] = (int32_t)chains[x].size();
+        xnode[x] = todo[x]; xlen[x] = (int32_t)chains[x].size();
         for (size_t i = 0; i < chains[x].size(); i++) xchain[(size_t)x * chain_cap + i] = chains[x][i];
     }
     const int tiles = (c.N + kTieTile - 1) / kTieTile, nbg = (c.TS + 63) / 64;
@@ -580,7 +588,9 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds)
                 pairs.push_back(P);
             }
     const int npairs = (int)pairs.size();
-    bool walk = getenv("RLHIP_TIE_WALK") != nullptr || npairs == 0 || (size_t)kTsWaves * c.TS * 4 > (size_t)60 * 1024;      // (huge threshold tables: the sort's cursors would not fit the LDS)
+    // short chains: the literal walk (one kernel, ~6 ns a document) beats the dozen launches and two more host round trips of the contiguous-chain path
+    static const size_t walk_max = getenv("RLHIP_TIE_WALK_MAX") ? (size_t)atoll(getenv("RLHIP_TIE_WALK_MAX")) : (size_t)24576;
+    bool walk = getenv("RLHIP_TIE_WALK") != nullptr || npairs == 0 || u_total <= walk_max || (size_t)kTsWaves * c.TS * 4 > (size_t)60 * 1024;      // (huge threshold tables: the sort's cursors would not fit the LDS)
     std::vector<int32_t> cnts((size_t)npairs * c.TS);
     if (!walk) {       // cumulative bin counts of the pairs (exact): where every bin's run starts in the sorted values
         if (cnts.size() * sizeof(int32_t) > t->tie_pin_cap) return fail(RL_ERR_UNSUPPORTED, "tie-break: too many (chain node, feature) pairs");
@@ -676,10 +686,10 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds)
         t->tie_spec_segs += nchunks;
     }
     const size_t tf_lds = std::max(fin_lds, std::min((size_t)96 * 1024, (size_t)chain_cap * c.TS * 8));       // staging of a feature's chain arrays; select_step afterwards
-    hipLaunchKernelGGL(k_tie_finish, dim3(1), dim3(kFinThreads), tf_lds, s, c, a, nodes_in_lds, (int)tf_lds);
+    hipLaunchKernelGGL(k_tie_finish, dim3(1), dim3(kFinThreads), tf_lds, s, c, a, nodes_in_lds, (int)tf_lds, deferred ? 1 : 0);
     RL_HIP(hipGetLastError());
     RL_HIP(hipStreamSynchronize(s));
-    t->tie_stalls++; t->tie_nodes += nx; t->tie_chain_nodes += nA;
+    t->tie_stalls++; t->tie_nodes += nx; t->tie_chain_nodes += nA; if (deferred) t->tie_batches++;
     for (auto &A : an) t->tie_chain_docs += A.count;
     t->tie_us += (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_begin).count();
     return RL_OK;
@@ -779,6 +789,7 @@ static int enqueue_round(rl_trainer *t)
     // enqueued meanwhile are no-ops; afterwards the host carries on from the device's own step count.  `extra`: the stalled select_step call and
     // its resumption count as steps of the device without committing a split.
     const auto stalled = [&](unsigned long long w) { return c.tie_on && (w >> 32) == t->tree_seq && ((w >> 31) & 1ull); };
+    bool defer_seen = false;       // the finished tree holds nodes whose stored threshold awaits the batched tie-break (progress word bit 30)
     int extra = 0, it = 0;
     bool saw_end = false;
     auto after_stall = [&](bool &ended) -> int {        // stream idle, tree stalled: resolve, then continue at the device's step
@@ -788,6 +799,7 @@ static int enqueue_round(rl_trainer *t)
         TreeState sth;
         RL_HIP(hipMemcpy(&sth, c.st, sizeof(sth), hipMemcpyDeviceToHost));
         ended = sth.done != 0;
+        if (ended) defer_seen = sth.defer_any != 0;
         it = sth.step;
         return RL_OK;
     };
@@ -832,15 +844,22 @@ static int enqueue_round(rl_trainer *t)
                 }
                 const int step_w = (int)((unsigned)(w & 0x7fffffffull) >> 1);
                 if (finished(w) && step_w <= it - t->step_ahead) break;
-            } else if (w < want && !finished(w)) {
-                const auto t0 = std::chrono::steady_clock::now();
-                unsigned spins = 0;
-                while ((w = __atomic_load_n(t->h_progress, __ATOMIC_ACQUIRE)) < want && !finished(w)) {
-                    if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) { throttle = false; break; }
+            } else {
+                // (bits 30 / 31 of the low word are flags: the step is compared field by field)
+                const auto behind = [&](unsigned long long v) {
+                    if ((v >> 32) != t->tree_seq) return true;                   // still the previous tree's word
+                    return (unsigned)((v & 0x3fffffffull) >> 1) < (unsigned)(it - t->step_ahead) && !(v & 1) && !((v >> 31) & 1);
+                };
+                if (behind(w)) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    unsigned spins = 0;
+                    while (behind(w = __atomic_load_n(t->h_progress, __ATOMIC_ACQUIRE))) {
+                        if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) { throttle = false; break; }
+                    }
                 }
             }
             if (!t->dist && stalled(w)) { it--; continue; }       // handled at the top of the loop
-            if (!t->dist && finished(w)) { saw_end = true; break; }
+            if (!t->dist && finished(w)) { saw_end = true; defer_seen = ((w >> 30) & 1ull) != 0; break; }
         }
         if (t->dist) {      // local child sizes are unknown in advance: count pass, then scatter
             hipLaunchKernelGGL(k_part_count, dim3(c.nTiles), dim3(kThreads), 0, s, c);
@@ -885,7 +904,7 @@ static int enqueue_round(rl_trainer *t)
             int rcs = after_stall(ended);
             if (rcs) return rcs;
             if (!ended) goto grow;
-        }
+        } else defer_seen = sth.defer_any != 0;
     }
     hipLaunchKernelGGL(k_leaf_table, dim3(1), dim3(kThreads), 0, s, c, t->leaf_chain, t->d_seg_buf);
     if (t->p.flags & RL_FLAG_SERIAL_CHAIN) {
@@ -956,6 +975,13 @@ static int enqueue_round(rl_trainer *t)
         hipLaunchKernelGGL(k_leaf_output, dim3((c.L + kThreads - 1) / kThreads), dim3(kThreads), 0, s, c, t->leaf_chain);
     }
     hipLaunchKernelGGL(k_score_update, dim3(std::min(4096, (c.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, c);
+    if (c.tie_on && defer_seen) {
+        // plateau ties of right children: the tree was grown with the partitions they all share; the thresholds the Java's rounding noise would
+        // store are decided now, in one batch (the leaf sums and the score update above are already enqueued and run meanwhile)
+        RL_HIP(hipStreamSynchronize(s));
+        int rcs = resolve_ties(t, fin_lds, nodes_in_lds, true);
+        if (rcs) return rcs;
+    }
     hipLaunchKernelGGL(k_export_tree, dim3(1), dim3(kThreads), 0, s, c, t->ens, m);
     RL_HIP(hipGetLastError());
     // per-round training metric (LambdaMART.java:216)

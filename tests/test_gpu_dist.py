@@ -135,8 +135,8 @@ def test_bench_entry_starts_its_own_ranks():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--shape", "c0", "--plain"] + extra,
                            env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-        assert len(lines) == 1, r.stdout[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1 and lines[0].startswith("{"), "stdout must hold the one JSON line and nothing else: " + r.stdout[-2000:]
         o = json.loads(lines[0])
         assert o["n_gpus"] == 2 and o["value"] > 0 and o["scaling"] == ("weak" if extra else "strong")
         ex = o["config"]["exchange_per_round_rank0"]
