@@ -243,6 +243,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--plain", action="store_true", help="timed region only: no CPU baseline, sustained run, node timing, membench or PMC passes")
     ap.add_argument("--metric", default="NDCG", help="train metric: NDCG (the BASELINE.json metric) | DCG | ERR | MAP (RankLib's own default is ERR@10)")
+    ap.add_argument("--first-tie", action="store_true", help="RL_FLAG_FIRST_TIE: exact ties keep the first candidate (no lazy Java-order tie-break)")
     ap.add_argument("--java-order", action="store_true", help="RL_FLAG_JAVA_ORDER: the strict mode (split gains from the Java's own f64 summation order)")
     ap.add_argument("--workload", default="train", help="train (default, the BASELINE.json metric) | infer (configs[4]: Ensemble.eval)")
     ap.add_argument("--scaling", default="strong", help="strong (default: the SAME data set sharded over --gpus ranks, what BASELINE.json configs[2] states) | "
@@ -291,6 +292,8 @@ def main():
     t_gen = time.time() - t0
 
     flags = 0 if args.no_timing else N.RL_FLAG_TIMING
+    if args.first_tie:
+        flags |= N.RL_FLAG_FIRST_TIE
     if args.java_order:
         flags |= N.RL_FLAG_JAVA_ORDER
         args.sustain = min(args.sustain, 20)
@@ -467,8 +470,8 @@ def main():
         out["config"]["sustained_over_rounds"] = args.sustain
     ts = g.array("TIE_STATS")
     out["config"]["tie_break"] = {
-        "mode": "lazy Java-order (exact ties re-decided in the reference's summation order, DESIGN.md 4.13)" if (world == 1 and not args.java_order) else
-                ("strict: every candidate from the Java-order histogram" if args.java_order else "first candidate in scan order (sharded run)"),
+        "mode": "lazy Java-order (exact ties re-decided in the reference's summation order, DESIGN.md 4.13)" if (world == 1 and not args.java_order and not args.first_tie) else
+                ("strict: every candidate from the Java-order histogram" if args.java_order else "first candidate in scan order (sharded run or --first-tie)"),
         "resolutions": int(ts[0]), "nodes": int(ts[1]), "chain_documents": int(ts[3]), "host_ms": float(ts[4]) / 1e3,
         "note": "whole run of this trainer (warm-up, timed, sustained and per-step-timing rounds)"}
     if "roofline" in out and "node_histograms" in out["roofline"]:
