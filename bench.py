@@ -428,6 +428,10 @@ def main():
             "traffic_source": ("live: bench.py re-ran itself under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); bytes = "
                                "%.1f x FETCH_SIZE + WRITE_SIZE per launch (factors: profiles/r02_fetch_calibration.txt)" % FETCH_FACTOR_WIDE) if pmc else None,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": per_launch_ms, "launches": int(n_root),
+            # what the kernel's layout actually streams: packed rows (one byte per bin id + a 16-bit mask per 16 features) when no
+            # threshold table has more than 257 entries -- fewer bytes than SURVEY.md 8d's b = 2 figure that `achieved` is defined on
+            "layout_bytes_per_launch": N_loc * (((n_feat + 15) // 16) * (18.0 if T_ <= 257 else 32.0) + 8.0),
+            "lds_atomics_per_s": None,
             "note": "algorithmic bytes = N_local*(F*2 B bin ids + 8 B fixed-point lambda); HIP events on the library stream",
             "measured_copy_GBps": copy_gbs, "measured_read_GBps": read_gbs, "measured_gather32_GBps": gather_gbs,
             "frac_of_measured_read": (achieved / read_gbs) if read_gbs else None,
