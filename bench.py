@@ -461,7 +461,7 @@ def main():
                                       "hist_nodes": node["ms_per_round"] if node else None}
     if world > 1:
         out["config"]["exchange_per_round_rank0"] = {"allreduce_calls": ds[0], "allreduce_bytes": ds[1], "allgather_calls": ds[2], "allgather_bytes_received": ds[3],
-                                                     "alltoall_calls": ds[4], "alltoall_bytes_received": ds[5],
+                                                     "alltoall_calls": ds[4], "alltoall_bytes_received": ds[5], "tie_break_calls": ds[6], "tie_break_bytes_received": ds[7],
                                                      "allgather_of_every_lambda_would_be_bytes": 16.0 * n_docs,
                                                      "transport": "host callbacks over gloo (test aid)" if os.environ.get("RLHIP_BENCH_TRANSPORT") == "gloo" else "RCCL",
                                                      "note": "payload handed to the transport by this rank per round: histogram limbs per growth step (all-reduce); lambda / weight of the "

@@ -232,9 +232,9 @@ int rl_dist_unique_id(void *id_out /* RL_UNIQUE_ID_BYTES */);       /* call on r
  * are summed across ranks with RCCL, per-query metric values are gathered in rank order. */
 int rl_dist_init(rl_trainer *t, const void *id, int32_t rank, int32_t n_ranks);
 
-/* Exchange volume of this rank since rl_dist_init: out[0..5] = all-reduce calls, all-reduce payload bytes, all-gather calls, all-gather
- * bytes received, all-to-all calls, all-to-all bytes received from OTHER ranks (zeros for an unsharded trainer).  bench.py prints the
- * per-round figures for N > 1. */
+/* Exchange volume of this rank since rl_dist_init: out[0..7] = all-reduce calls, all-reduce payload bytes, all-gather calls, all-gather
+ * bytes received, all-to-all calls, all-to-all bytes received from OTHER ranks -- the per-round pattern -- and, counted apart, the calls and
+ * bytes received of the lazy tie-break's exchanges (zeros for an unsharded trainer).  bench.py prints the per-round figures for N > 1. */
 int rl_dist_stats(const rl_trainer *t, int64_t *out);
 
 /* The same sharded training over a caller-supplied transport instead of RCCL (gloo, MPI, shared memory ...):

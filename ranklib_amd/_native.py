@@ -294,8 +294,8 @@ class Trainer:
 
     def dist_stats(self):
         """[all-reduce calls, all-reduce bytes, all-gather calls, all-gather bytes received, all-to-all calls, all-to-all bytes received from
-        other ranks] of this rank so far"""
-        out = np.zeros(6, np.int64)
+        other ranks, calls / bytes received of the lazy tie-break's exchanges] of this rank so far"""
+        out = np.zeros(8, np.int64)
         check(lib().rl_dist_stats(self.h, out.ctypes.data))
         return out
 

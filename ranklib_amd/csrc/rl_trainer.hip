@@ -468,6 +468,7 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool de
     Ctx &c = t->ctx;
     hipStream_t s = t->stream;
     const auto t_begin = std::chrono::steady_clock::now();
+    struct TieScope { DistBackend *d; TieScope(DistBackend *d_) : d(d_) { if (d) d->tie_scope = true; } ~TieScope() { if (d) d->tie_scope = false; } } tie_scope(t->dist.get());
     // small reads come back through one pinned buffer (a pageable copy costs tens of microseconds each)
     const size_t pin_need = sizeof(TreeState) + (size_t)(c.NC + 2) * sizeof(NodeRec) + (size_t)kTieMaxChain * c.F * 4 + ((size_t)1 << 20);
     if (t->tie_pin_cap < pin_need) {
@@ -495,6 +496,7 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool de
         auto it = a_of.find(x);
         if (it != a_of.end()) return it->second;
         TieNode A; A.node = x; A.pred0 = (int)preds.size(); A.npred = 0; A.is_root = (x == 0) ? 1 : 0; A.list0 = 0; A.count = nodes[x].gcount;
+        A.gcount = nodes[x].gcount; A.pad = 0;             // count: this rank's members (the device sets it; == gcount on one GPU)
         for (int ch = x; nodes[ch].parent >= 0; ch = nodes[ch].parent) {
             const NodeRec &P = nodes[nodes[ch].parent];
             preds.push_back(TiePred{P.best_f, P.best_t, P.pl == ch ? 1 : 0});
@@ -517,15 +519,17 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool de
         chain_cap = std::max(chain_cap, chains[x].size());
     }
     const int nA = (int)an.size();
+    const bool sharded = t->dist && t->n_ranks > 1;       // the members of a chain node are spread over the ranks: their values are gathered (below)
+    const int R = sharded ? t->n_ranks : 1;
     if (nA > kTieMaxChain) return fail(RL_ERR_UNSUPPORTED, "tie-break: derivation chain of " + std::to_string(nA) + " nodes");
     size_t list_total = 0, u_total = 0;
     std::vector<long long> u0((size_t)nA);
     int maxcnt = 1;
     for (int i = 0; i < nA; i++) {
         TieNode &A = an[i];
-        if (!A.is_root) { A.list0 = (int32_t)list_total; list_total += (size_t)A.count; }
-        u0[i] = (long long)u_total; u_total += (size_t)A.count;
-        maxcnt = std::max(maxcnt, A.count);
+        if (!A.is_root) { A.list0 = (int32_t)list_total; list_total += (size_t)std::min(A.gcount, c.N); }
+        u0[i] = (long long)u_total; u_total += (size_t)A.gcount;
+        maxcnt = std::max(maxcnt, std::min(A.gcount, c.N));
     }
     if (list_total > ((size_t)1 << 31) - 1) return fail(RL_ERR_UNSUPPORTED, "tie-break: member lists beyond 2^31 entries");
     std::vector<int32_t> xlen((size_t)nx), xchain((size_t)nx * chain_cap, 0), xnode((size_t)nx);
@@ -541,7 +545,7 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool de
     TieArena ar;
     TieArgs a;
     long long *d_u0 = nullptr;
-    std::vector<int32_t> need((size_t)nA * c.F);
+    std::vector<int32_t> need((size_t)nA * c.F), lcnt((size_t)nA, 0);
     // (a lambda: when stage 2 turns out to need a larger arena, the arena moves and stage 1 is simply run again)
     auto stage1 = [&]() -> int {
         ar = TieArena(); ar.base = (char *)t->tie_buf; ar.cap = t->tie_cap;
@@ -571,26 +575,32 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool de
             hipLaunchKernelGGL(k_tie_scatter, dim3(tiles, nA), dim3(kThreads), 0, s, c, a, tiles);
         }
         RL_HIP(hipMemcpyAsync(pin, a.need, need.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        RL_HIP(hipMemcpyAsync(pin + need.size() * sizeof(int32_t), a.an, (size_t)nA * sizeof(TieNode), hipMemcpyDeviceToHost, s));
         RL_HIP(hipStreamSynchronize(s));
         memcpy(need.data(), pin, need.size() * sizeof(int32_t));
+        for (int i = 0; i < nA; i++) {      // this rank's member counts (k_tie_scan)
+            TieNode A; memcpy(&A, pin + need.size() * sizeof(int32_t) + (size_t)i * sizeof(TieNode), sizeof(A));
+            lcnt[i] = an[i].is_root ? c.N : (any_list ? A.count : an[i].gcount);
+        }
         return RL_OK;
     };
     { int rc1 = stage1(); if (rc1) return rc1; }
     // ---- stage 2: the needed (chain node, feature) pairs, their bins' sizes, the chains and their segments
     std::vector<TiePair> pairs;
-    size_t v_total = u_total;
+    size_t v_total = u_total, m_total = 0;
     int tiles_max = 1;
     for (int i = 0; i < nA; i++)
         for (int f = 0; f < c.F; f++)
             if (need[(size_t)i * c.F + f]) {
-                TiePair P; P.a = i; P.f = f; P.tiles = (an[i].count + kTsTile - 1) / kTsTile; P.pad = 0; P.v0 = (long long)v_total;
-                v_total += (size_t)an[i].count; tiles_max = std::max(tiles_max, P.tiles);
+                TiePair P; P.a = i; P.f = f; P.tiles = (an[i].gcount + kTsTile - 1) / kTsTile; P.pad = 0; P.v0 = (long long)v_total; P.m0 = (long long)m_total;
+                v_total += (size_t)an[i].gcount; m_total += (size_t)an[i].gcount; tiles_max = std::max(tiles_max, P.tiles);
                 pairs.push_back(P);
             }
     const int npairs = (int)pairs.size();
     // short chains: the literal walk (one kernel, ~6 ns a document) beats the dozen launches and two more host round trips of the contiguous-chain path
     static const size_t walk_max = getenv("RLHIP_TIE_WALK_MAX") ? (size_t)atoll(getenv("RLHIP_TIE_WALK_MAX")) : (size_t)24576;
     bool walk = getenv("RLHIP_TIE_WALK") != nullptr || npairs == 0 || u_total <= walk_max || (size_t)kTsWaves * c.TS * 4 > (size_t)60 * 1024;      // (huge threshold tables: the sort's cursors would not fit the LDS)
+    if (sharded) walk = false;                // the walk reads this rank's documents only; rl_init keeps the tie-break off for sharded runs with huge tables
     std::vector<int32_t> cnts((size_t)npairs * c.TS);
     if (!walk) {       // cumulative bin counts of the pairs (exact): where every bin's run starts in the sorted values
         if (cnts.size() * sizeof(int32_t) > t->tie_pin_cap) return fail(RL_ERR_UNSUPPORTED, "tie-break: too many (chain node, feature) pairs");
@@ -612,7 +622,7 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool de
     std::vector<int32_t> &h_nthr = t->h_nthr;
     if (!walk) {
         if ((int)h_nthr.size() != c.F) { h_nthr.resize(c.F); RL_HIP(hipMemcpy(h_nthr.data(), c.nthr, c.F * sizeof(int32_t), hipMemcpyDeviceToHost)); }
-        for (int i = 0; i < nA; i++) add_chain(u0[i], an[i].count, -(i + 1));
+        for (int i = 0; i < nA; i++) add_chain(u0[i], an[i].gcount, -(i + 1));
         for (int p = 0; p < npairs; p++) {
             const int32_t *cc = cnts.data() + (size_t)p * c.TS;
             for (int b = 0; b < h_nthr[pairs[p].f]; b++) {
@@ -622,7 +632,10 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool de
         }
     }
     const int nch = (int)chs.size(), nwin = (int)win_chain.size(), nchunks = (int)chunk_chain.size();
-    const size_t spec_bytes = v_total * 8 + (size_t)npairs * tiles_max * c.TS * 4 + (size_t)nwin * (16 + 16 + 4) + (size_t)nchunks * (4 + 16 + 8 + 8 * kSpW + 4) +
+    size_t l_u = 0, l_m = 0;                 // this rank's members of the chain nodes / of the pairs' chain nodes
+    for (int i = 0; i < nA; i++) l_u += (size_t)lcnt[i];
+    for (int p = 0; p < npairs; p++) l_m += (size_t)lcnt[pairs[p].a];
+    const size_t spec_bytes = (m_total + 64) * 2 + (sharded ? (l_u + u_total + 64) * 8 + (l_m + m_total + 64) * 2 + (size_t)(R + 1) * nA * 4 : 0) + (size_t)(nA + 2 * npairs + 8) * 8 + v_total * 8 + (size_t)npairs * tiles_max * c.TS * 4 + (size_t)nwin * (16 + 16 + 4) + (size_t)nchunks * (4 + 16 + 8 + 8 * kSpW + 4) +
                               (size_t)nch * (16 + 8 + 8 + sizeof(TieChain)) + (size_t)npairs * sizeof(TiePair) + (size_t)(nwin + nchunks) * 4 + 64 * 256;
     if (!walk && fixed_bytes + spec_bytes + ((size_t)1 << 20) > t->tie_cap) {
         // the arena has to grow: it moves, so stage 1 runs again in the new one (and later calls ask for this much up front)
@@ -643,10 +656,15 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool de
         auto put = [&](const void *src, size_t bytes) { const size_t o = (blob.size() + 15) & ~(size_t)15; blob.resize(o + bytes); if (bytes) memcpy(blob.data() + o, src, bytes); return o; };
         const size_t o_pairs = put(pairs.data(), npairs * sizeof(TiePair)), o_chs = put(chs.data(), nch * sizeof(TieChain));
         const size_t o_winc = put(win_chain.data(), nwin * sizeof(int32_t)), o_chunkc = put(chunk_chain.data(), nchunks * sizeof(int32_t));
+        std::vector<long long> m0s((size_t)npairs); std::vector<int32_t> pair_a((size_t)npairs);
+        for (int p2 = 0; p2 < npairs; p2++) { m0s[p2] = pairs[p2].m0; pair_a[p2] = pairs[p2].a; }
+        const size_t o_m0 = put(m0s.data(), npairs * sizeof(long long)), o_paira = put(pair_a.data(), npairs * sizeof(int32_t));
         char *d_blob = ar.take<char>(blob.size() + 16);
         RL_HIP(hipMemcpyAsync(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, s));
         TiePair *d_pairs = (TiePair *)(d_blob + o_pairs); TieChain *d_chs = (TieChain *)(d_blob + o_chs);
         int32_t *d_winc = (int32_t *)(d_blob + o_winc), *d_chunkc = (int32_t *)(d_blob + o_chunkc);
+        long long *d_m0 = (long long *)(d_blob + o_m0); int32_t *d_paira = (int32_t *)(d_blob + o_paira);
+        (void)d_paira;
         sp.vals = ar.take<double>(v_total + 1); sp.tbin = ar.take<int32_t>((size_t)npairs * tiles_max * c.TS);
         sp.wsum = ar.take<double2>(nwin + 1); sp.wpre = ar.take<double2>(nwin + 1);
         sp.cstart = ar.take<int32_t>(nchunks + 1); sp.cpre = ar.take<double2>(nchunks + 1);
@@ -655,7 +673,54 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool de
         sp.open = ar.take<int32_t>(4);
         if (ar.used > t->tie_cap) return fail(RL_ERR_HIP, "tie-break: scratch arena too small (internal error)");
         sp.pairs = d_pairs; sp.chains = d_chs; sp.win_chain = d_winc; sp.chunk_chain = d_chunkc; sp.u0 = d_u0;
-        hipLaunchKernelGGL(k_tie_gather, dim3(std::min(4096, (maxcnt + kThreads - 1) / kThreads), nA), dim3(kThreads), 0, s, c, a, sp);
+        sp.mb = ar.take<uint16_t>(m_total + 64);
+        const dim3 ggrid_u(std::min(4096, (maxcnt + kThreads - 1) / kThreads), nA), ggrid_m(std::min(4096, (maxcnt + kThreads - 1) / kThreads), std::max(npairs, 1));
+        if (!sharded) {
+            // one GPU: this rank's members ARE the members -- lambda and bins go straight to their global places
+            hipLaunchKernelGGL(k_tie_gather, ggrid_u, dim3(kThreads), 0, s, c, a, sp.vals, (const long long *)d_u0);
+            if (npairs > 0) hipLaunchKernelGGL(k_tie_gather_bins, ggrid_m, dim3(kThreads), 0, s, c, a, (const TiePair *)d_pairs, sp.mb, (const long long *)d_m0);
+        } else {
+            // sharded: rank order is global document order, so the global arrays are the ranks' pieces behind each other.  Every rank gathers its
+            // own pieces, all ranks exchange them (an all-gather of variable pieces through the all-to-all primitive), and every rank then runs the
+            // SAME evaluation on the same global arrays -- the decision is rank-invariant by construction.
+            std::vector<long long> lu0((size_t)nA), lm0((size_t)std::max(npairs, 1));
+            { long long o = 0; for (int i = 0; i < nA; i++) { lu0[i] = o; o += lcnt[i]; } }
+            { long long o = 0; for (int p2 = 0; p2 < npairs; p2++) { lm0[p2] = o; o += lcnt[pairs[p2].a]; } }
+            long long *d_lu0 = ar.take<long long>(nA), *d_lm0 = ar.take<long long>(std::max(npairs, 1));
+            int32_t *d_lcnt = ar.take<int32_t>(nA), *d_cntR = ar.take<int32_t>((size_t)R * nA);
+            double *d_ul = ar.take<double>(l_u + 8), *d_urecv = ar.take<double>(u_total + 8);
+            uint16_t *d_mbl = ar.take<uint16_t>(l_m + 8), *d_mbrecv = ar.take<uint16_t>(m_total + 8);
+            if (ar.used > t->tie_cap) return fail(RL_ERR_HIP, "tie-break: scratch arena too small (internal error)");
+            RL_HIP(hipMemcpyAsync(d_lu0, lu0.data(), nA * sizeof(long long), hipMemcpyHostToDevice, s));
+            if (npairs > 0) RL_HIP(hipMemcpyAsync(d_lm0, lm0.data(), npairs * sizeof(long long), hipMemcpyHostToDevice, s));
+            RL_HIP(hipMemcpyAsync(d_lcnt, lcnt.data(), nA * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_tie_gather, ggrid_u, dim3(kThreads), 0, s, c, a, d_ul, (const long long *)d_lu0);
+            if (npairs > 0) hipLaunchKernelGGL(k_tie_gather_bins, ggrid_m, dim3(kThreads), 0, s, c, a, (const TiePair *)d_pairs, d_mbl, (const long long *)d_lm0);
+            int rcd = t->dist->allgather(d_lcnt, d_cntR, (size_t)nA * sizeof(int32_t), s);
+            if (rcd) return rcd;
+            std::vector<int32_t> cntR((size_t)R * nA);
+            RL_HIP(hipMemcpyAsync(pin, d_cntR, cntR.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            RL_HIP(hipStreamSynchronize(s));
+            memcpy(cntR.data(), pin, cntR.size() * sizeof(int32_t));
+            std::vector<int64_t> scount(R), sdispl(R, 0), rcount(R), rdispl(R);
+            {   // lambda pieces
+                int64_t o = 0;
+                for (int r = 0; r < R; r++) { int64_t n = 0; for (int i = 0; i < nA; i++) n += cntR[(size_t)r * nA + i]; rcount[r] = n * 8; rdispl[r] = o; o += n * 8; scount[r] = (int64_t)l_u * 8; }
+                if ((size_t)o != u_total * 8) return fail(RL_ERR_COMM, "tie-break: the ranks' member counts do not add up to the nodes' document counts");
+                rcd = t->dist->alltoallv(d_ul, scount.data(), sdispl.data(), d_urecv, rcount.data(), rdispl.data(), s);
+                if (rcd) return rcd;
+                hipLaunchKernelGGL(k_tie_place<double>, dim3(nA, R), dim3(kThreads), 0, s, (const double *)d_urecv, sp.vals, (const int32_t *)d_cntR, (const int32_t *)nullptr,
+                                   (const long long *)d_u0, nA, nA, R);
+            }
+            if (npairs > 0) {   // bins of the pairs
+                int64_t o = 0;
+                for (int r = 0; r < R; r++) { int64_t n = 0; for (int p2 = 0; p2 < npairs; p2++) n += cntR[(size_t)r * nA + pairs[p2].a]; rcount[r] = n * 2; rdispl[r] = o; o += n * 2; scount[r] = (int64_t)l_m * 2; }
+                rcd = t->dist->alltoallv(d_mbl, scount.data(), sdispl.data(), d_mbrecv, rcount.data(), rdispl.data(), s);
+                if (rcd) return rcd;
+                hipLaunchKernelGGL(k_tie_place<uint16_t>, dim3(npairs, R), dim3(kThreads), 0, s, (const uint16_t *)d_mbrecv, sp.mb, (const int32_t *)d_cntR, (const int32_t *)d_paira,
+                                   (const long long *)d_m0, npairs, nA, R);
+            }
+        }
         hipLaunchKernelGGL(k_ts_count, dim3(tiles_max, npairs), dim3(kThreads), (size_t)c.TS * 4, s, c, a, sp);
         hipLaunchKernelGGL(k_ts_scan, dim3(npairs, nbg), dim3(64), 0, s, c, a, sp);
         hipLaunchKernelGGL(k_ts_scatter, dim3(tiles_max, npairs), dim3(kTsWaves * 64), (size_t)kTsWaves * c.TS * 4, s, c, a, sp);
@@ -830,7 +895,7 @@ static int enqueue_round(rl_trainer *t)
                 // that looks early and one that looks late take the same decision at the same `it`.
                 unsigned spins = 0;
                 const auto t0w = std::chrono::steady_clock::now();
-                while (w < want && !finished(w)) {
+                while ((w & ~(3ull << 30)) < want && !finished(w) && !stalled(w)) {       // (bits 30 / 31 of the low word are flags)
                     w = __atomic_load_n(t->h_progress, __ATOMIC_ACQUIRE);
                     if ((++spins & 0xfffff) == 0) {
                         const hipError_t q = hipStreamQuery(s);
@@ -842,8 +907,19 @@ static int enqueue_round(rl_trainer *t)
                                                      " of tree " + std::to_string(t->tree_seq) + " (a rank of the job is missing from a collective?)");
                     }
                 }
-                const int step_w = (int)((unsigned)(w & 0x7fffffffull) >> 1);
-                if (finished(w) && step_w <= it - t->step_ahead) break;
+                const int step_w = (int)((unsigned)(w & 0x3fffffffull) >> 1);
+                if (finished(w) && step_w <= it - t->step_ahead) { saw_end = true; defer_seen = ((w >> 30) & 1ull) != 0; break; }
+                // a stalled tree (rl_tie.inc): the word keeps the step at which it stalled, so -- as for the end of the tree -- every rank acts on
+                // it at the same `it`, after the same number of (empty) steps and their collectives
+                if (stalled(w) && step_w <= it - t->step_ahead) {
+                    RL_HIP(hipStreamSynchronize(s));
+                    bool ended = false;
+                    int rcs = after_stall(ended);
+                    if (rcs) return rcs;
+                    if (ended) { saw_end = true; break; }
+                    it--;
+                    continue;
+                }
             } else {
                 // (bits 30 / 31 of the low word are flags: the step is compared field by field)
                 const auto behind = [&](unsigned long long v) {
@@ -880,11 +956,19 @@ static int enqueue_round(rl_trainer *t)
             // Sharded runs pay a collective per step even when the tree is already finished, so the host looks at the
             // (rank-invariant) `done` flag now and then and stops enqueuing: a stream sync costs far less than the
             // all-reduces of ~20 empty steps.  One GPU keeps the fully asynchronous schedule (an empty step is 3 tiny launches).
-            if (!c.progress && it + 1 < steps && it >= 7 && (it - 7) % 3 == 0) {
-                int32_t done = 0;
+            if (!c.progress && it + 1 < steps + extra && ((it >= 7 && (it - 7) % 3 == 0) || c.tie_on)) {
+                TreeState sth;
                 RL_HIP(hipStreamSynchronize(s));
-                RL_HIP(hipMemcpy(&done, &c.st->done, sizeof(done), hipMemcpyDeviceToHost));
-                if (done) break;
+                RL_HIP(hipMemcpy(&sth, c.st, sizeof(sth), hipMemcpyDeviceToHost));
+                if (sth.stall_n > 0) {       // (without a progress word every step of a tie-breaking sharded run is looked at: rank-invariant by construction)
+                    bool ended = false;
+                    int rcs = after_stall(ended);
+                    if (rcs) return rcs;
+                    if (ended) { saw_end = true; break; }
+                    it--;
+                    continue;
+                }
+                if (sth.done) { saw_end = true; defer_seen = sth.defer_any != 0; break; }
             }
         } else if (c.java) {
             hipLaunchKernelGGL(k_jgather, dim3(c.nTiles), dim3(kThreads), 0, s, c, 0);
@@ -1327,7 +1411,7 @@ int rl_init(rl_trainer *t)
     // lazy Java-order tie-break (rl_tie.inc): the default path's exact ties resolved as the Java's summation order resolves them.  Not with
     // feature sampling (the Java's draw is unseeded: nothing to match), not sharded (the Java's order is ONE sequence over all documents), not in
     // the strict mode (every candidate already comes from the Java-order histogram)
-    c.tie_on = (c.fs_size == F && !t->dist && !(t->p.flags & (RL_FLAG_JAVA_ORDER | RL_FLAG_FIRST_TIE)) && !getenv("RLHIP_TIE_OFF")) ? 1 : 0;
+    c.tie_on = (c.fs_size == F && !(t->p.flags & (RL_FLAG_JAVA_ORDER | RL_FLAG_FIRST_TIE)) && !getenv("RLHIP_TIE_OFF")) ? 1 : 0;      // (sharded runs: decided below, once TS is known)
     // rows of a ranked list whose pairs the lambda loop visits (LambdaMART.java:375-377: j <= cutoff or k <= cutoff); for
     // NDCG / DCG / ERR row `cutoff` itself only holds zero swap changes
     c.k = (t->p.metric == RL_METRIC_MAP) ? t->p.metric_k + 1 : t->p.metric_k;
@@ -1404,6 +1488,9 @@ int rl_init(rl_trainer *t)
         c.live = d_live; c.n_live = (int32_t)live.size();
     }
     if ((size_t)TS * 12 > (size_t)kHistLdsBytes) return fail(RL_ERR_UNSUPPORTED, "too many threshold candidates for the LDS histogram");
+    // sharded runs evaluate the tie-break on gathered arrays through the contiguous-chain path only: with threshold tables too large for its sort
+    // (the literal walk reads one rank's documents) they keep the first candidate.  TS is the same on every rank, so is the decision.
+    if (t->dist && t->n_ranks > 1 && (size_t)kTsWaves * TS * 4 > (size_t)60 * 1024) c.tie_on = 0;
     if (t->p.n_leaves == -1) {      // -leaf -1: the node histograms are sized for floor(N / mls) leaves -- say so before an allocation fails
         const double need = (double)c.NC * F * TS * ((t->p.flags & RL_FLAG_JAVA_ORDER) ? 28.0 : 20.0);
         size_t mem_free = 0, mem_total = 0;
@@ -2001,10 +2088,10 @@ int rl_dist_stats(const rl_trainer *t, int64_t *out)
 {
     if (check_trainer(t)) return RL_ERR_INVALID;
     if (!out) return fail(RL_ERR_INVALID, "null argument");
-    out[0] = out[1] = out[2] = out[3] = out[4] = out[5] = 0;
+    for (int i = 0; i < 8; i++) out[i] = 0;
     if (t->dist) {
         out[0] = t->dist->n_allreduce; out[1] = t->dist->b_allreduce; out[2] = t->dist->n_allgather; out[3] = t->dist->b_allgather;
-        out[4] = t->dist->n_alltoall; out[5] = t->dist->b_alltoall;
+        out[4] = t->dist->n_alltoall; out[5] = t->dist->b_alltoall; out[6] = t->dist->n_tie; out[7] = t->dist->b_tie;
     }
     return RL_OK;
 }

@@ -22,10 +22,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def single(n_docs, n_feat, kind, seed, leaves, rounds, dist_mode=None, ranker="LAMBDAMART", metric="NDCG", k=10, opts=()):
     X, lab, qoff = synth.make_dataset(n_docs, n_feat, kind, seed_offset=seed)
-    # RL_FLAG_FIRST_TIE: sharded runs keep the first of exactly tied candidates (the Java's summation order is one sequence over all documents);
-    # with the flag a one-GPU run does the same, and the two must agree bit for bit
+    # default flags on both sides: sharded runs re-decide exact ties in the Java's summation order as well (the members' values are gathered,
+    # every rank evaluates the same global chains) -- k shards must equal one shard in the stored (feature, threshold) pairs too
     g = N.Trainer(n_trees=rounds, n_leaves=-1 if "leafm1" in opts else leaves, ranker=ranker, metric=metric, metric_k=k,
-                  min_leaf_support=40 if "leafm1" in opts else 1, flags=N.RL_FLAG_FIRST_TIE)
+                  min_leaf_support=40 if "leafm1" in opts else 1)
     g.set_train(X, lab, qoff)
     if "qrel" in opts:       # as tests/dist_worker.py
         qi = np.arange(len(qoff) - 1)
@@ -75,13 +75,15 @@ def test_shard_sizes_straddle_a_power_of_two():
     assert min(sizes) < 8191 < max(sizes), sizes
 
 
+CFG_TIES = (2500, 5, "mslr", 4, 31, 4)    # small nodes, five features: exact ties in every round -- the sharded lazy tie-break has to run (and to agree with one GPU)
 CFG31 = (9000, 24, "mslr", 4, 31, 4)      # 30 growth steps allowed, trees finish after ~10: the ranks must stop enqueuing at the same step
 
 
 @pytest.mark.parametrize("world,ranker,metric,k,cfg", [(2, "LAMBDAMART", "NDCG", 10, CFG), (3, "LAMBDAMART", "NDCG", 10, CFG),
                                                         (2, "MART", "NDCG", 10, CFG), (2, "LAMBDAMART", "MAP", 0, CFG),
                                                         (3, "LAMBDAMART", "ERR", 10, CFG), (2, "LAMBDAMART", "NDCG", 10, CFG31),
-                                                        (3, "MART", "NDCG", 10, CFG31), (2, "LAMBDAMART", "NDCG", 10, CFG2K)])
+                                                        (3, "MART", "NDCG", 10, CFG31), (2, "LAMBDAMART", "NDCG", 10, CFG2K),
+                                                        (2, "LAMBDAMART", "NDCG", 10, CFG_TIES), (3, "LAMBDAMART", "NDCG", 10, CFG_TIES)])
 def test_k_shards_equal_one_shard(world, ranker, metric, k, cfg, tmp_path):
     CFG = cfg
     ref = single(*CFG, ranker=ranker, metric=metric, k=k)
@@ -99,6 +101,8 @@ def test_k_shards_equal_one_shard(world, ranker, metric, k, cfg, tmp_path):
     # of the leaves it owns that lives elsewhere -- never the 16 N of an all-gather of every document -- and the all-gathers that remain
     # (leaf tables, 2 L float sums, per-query metric values) are small change
     st = z["dist_stats"].astype(np.float64)
+    if cfg is CFG_TIES:      # the tie-break ran sharded: resolutions, and exchanges of the chain nodes' values counted apart from the per-round pattern
+        assert z["tie_stats"][0] > 0 and st[6] > 0 and st[7] > 0, (z["tie_stats"], st)
     assert st[4] == rounds and st[5] > 0
     assert st[5] / rounds <= 16.0 * CFG[0] * (world - 1) / world * 0.95, st
     # (st[3], the all-gather bytes, also holds rl_init's one-off exchange of the distinct-value sets; the per-round figure is checked through
@@ -162,7 +166,7 @@ def test_validation_set_under_sharding(world, tmp_path):
     X, lab, qoff = synth.make_dataset(cfg[0], cfg[1], cfg[2], seed_offset=cfg[3])
     Xv, lv, qv = synth.make_dataset(cfg[0] // 3, cfg[1], cfg[2], seed_offset=cfg[3] + 77)
     lv = lv[::-1].copy()                      # as tests/dist_worker.py does
-    g = N.Trainer(n_trees=cfg[5], n_leaves=cfg[4], early_stop_rounds=1, flags=N.RL_FLAG_FIRST_TIE)
+    g = N.Trainer(n_trees=cfg[5], n_leaves=cfg[4], early_stop_rounds=1)
     g.set_train(X, lab, qoff); g.set_validation(Xv, lv, qv); g.init()
     mets, vmets = [], []
     for _ in range(cfg[5]):
