@@ -68,8 +68,9 @@ enum {                                  /* rl_params.flags */
     RL_FLAG_SERIAL_CHAIN = 4,           /* evaluate the float running sums with the literal serial kernel instead of
                                            the exact parallel scheme (same results; for cross-checks) */
     RL_FLAG_FIRST_TIE = 32,             /* exact ties between split candidates keep the first one in scan order instead of being re-decided in the Java's
-                                           summation order (the lazy tie-break; default on one GPU without feature sampling).  This is what
-                                           sharded runs do anyway: a one-GPU run with the flag equals a sharded run bit for bit. */
+                                           summation order (the lazy tie-break, DESIGN.md 4.13: default, also for sharded runs; never with feature sampling).
+                                           Faster where nodes are tiny or columns sparse; the trees differ from the reference's only in the stored threshold
+                                           inside an empty-bin plateau / in which of two equivalent features is named. */
     RL_FLAG_JAVA_ORDER = 16             /* strict mode: split gains and node deviances come from the f64 histogram RankLib itself
                                            would hold -- every (feature, bin) sum accumulated sequentially in ascending sample
                                            order (FeatureHistogram.java:126-146,166-195), sequential prefix, right sibling =
