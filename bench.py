@@ -416,6 +416,15 @@ def main():
         except Exception as ex:       # noqa: BLE001
             sys.stderr.write("membench failed: %r\n" % (ex,))
     pmc = None if (args.no_pmc or world != 1) else live_pmc(args.shape)
+    lds_atomics = None
+    try:      # what the root pass is actually bound by: one ds_add_u64 per (document, feature) outside the feature's most populated bin
+        cnt_cum, nb_ = g.array("ROOT_COUNT").astype(np.int64), g.array("NBINS")
+        lds_atomics = 0.0
+        for f_ in range(n_feat):
+            per_bin = np.diff(np.concatenate([[0], cnt_cum[f_, :nb_[f_]]]))
+            lds_atomics += float(per_bin.sum() - per_bin.max()) * (N_loc / max(float(n_docs), 1.0) if world > 1 else 1.0)
+    except Exception as ex:       # noqa: BLE001
+        sys.stderr.write("root-pass atomics count failed: %r\n" % (ex,))
     if n_root > 0:
         per_launch_ms = ms_root / n_root
         alg_bytes = bytes_root / n_root
@@ -431,7 +440,7 @@ def main():
             # what the kernel's layout actually streams: packed rows (one byte per bin id + a 16-bit mask per 16 features) when no
             # threshold table has more than 257 entries -- fewer bytes than SURVEY.md 8d's b = 2 figure that `achieved` is defined on
             "layout_bytes_per_launch": N_loc * (((n_feat + 15) // 16) * (18.0 if T_ <= 257 else 32.0) + 8.0),
-            "lds_atomics_per_s": None,
+            "lds_atomics_per_launch": lds_atomics, "lds_atomics_per_cu_clock": (lds_atomics / (per_launch_ms * 1e-3) / (256 * 2.4e9)) if lds_atomics else None,
             "note": "algorithmic bytes = N_local*(F*2 B bin ids + 8 B fixed-point lambda); HIP events on the library stream",
             "measured_copy_GBps": copy_gbs, "measured_read_GBps": read_gbs, "measured_gather32_GBps": gather_gbs,
             "frac_of_measured_read": (achieved / read_gbs) if read_gbs else None,
