@@ -281,9 +281,11 @@ enum {
                                    SURVEY.md 8d times N), committed split nodes (nu times N) */
     RL_ARR_SPARSE_INFO = 19,    /* int64[4]: 16-feature groups whose root histogram comes from sparse-column entry lists (rl_csc.inc), entries,
                                    groups read as dense rows, live columns in the sparse groups */
-    RL_ARR_TIE_STATS = 21,      /* int64[8] cumulative, the lazy Java-order tie-break: times the host resolved a stalled tree, nodes whose tied
-                                   best split was re-decided in the Java's summation order, nodes and documents of the derivation chains that were summed,
-                                   host microseconds spent resolving, chain segments evaluated speculatively, candidate-window misses, segments run serially */
+    RL_ARR_TIE_STATS = 21,      /* int64[10] cumulative, the lazy Java-order tie-break: resolutions run by the host (stalled trees + batches), nodes
+                                   whose tied best split was re-decided in the Java's summation order, nodes and documents of the derivation chains that were summed,
+                                   host microseconds spent resolving, chain segments evaluated speculatively, candidate-window misses, segments run serially,
+                                   [8] of the resolutions the batches at the end of a tree (deferred ties), [9] trees grown a second time (a deferred tie over
+                                   several features did not cut the node one way) */
     RL_ARR_STEP_LOG = 20,       /* int32[8 + 8 * 8192], only with RLHIP_STEPLOG=1 in the environment of rl_init (else zeros): [0] = entries written; entry e at
                                    8 + 8 e: {tree, 0, growth step, slot, documents of the split node, documents of the accumulated child, tie flag, slots of the
                                    step} or {tree, 1, tie kind (1 = thresholds of one feature, 2 = several features), right child?, documents, largest node of

@@ -109,7 +109,8 @@ struct Ctx {
                                   // 2 = ((sum >> 44) << 32 | count, low limb) when the data set has fewer than 2^25 documents
     int32_t fs_size;              // features a split attempt looks at: F, or (int)(rate * F) with feature sampling (Random Forests)
     unsigned long long seed;      // rl_params.seed
-    int32_t tie_on;          // lazy Java-order tie-break (rl_tie.inc): no feature sampling, not the strict mode, not RL_FLAG_FIRST_TIE
+    int32_t tie_on;          // bit 0: lazy Java-order tie-break (rl_tie.inc): no feature sampling, not the strict mode, not RL_FLAG_FIRST_TIE;
+                             // bit 1: ties over several features that share one cut are deferred to the end of the tree (one GPU)
     int32_t mart, metric;    // MART leaf rule (learning/tree/MART.java); RL_METRIC_* of the train metric
     long long *dist_buf;     // [kSpec][F*TS*3 + 4] int64 limbs of the histograms being all-reduced (multi-GPU only)
     // static per data set

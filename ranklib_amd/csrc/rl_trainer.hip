@@ -97,7 +97,9 @@ struct rl_trainer {
     unsigned long long chain_seq = 0; std::vector<void *> pinned;     // chain pass tags; pinned words of the chains (freed in rl_destroy)
     int32_t synced_rounds = 0;
     long long tie_stalls = 0, tie_nodes = 0, tie_chain_nodes = 0, tie_chain_docs = 0;      // lazy tie-break (rl_tie.inc): resolutions run, nodes resolved, chain nodes / documents summed
-    long long tie_batches = 0;      // of the resolutions, the batched ones at the end of a tree (deferred plateau ties)
+    long long tie_batches = 0;      // of the resolutions, the batched ones at the end of a tree (deferred ties)
+    long long tie_phase_us[6] = {0, 0, 0, 0, 0, 0};   // RLHIP_TIE_PROF: host microseconds per phase of resolve_ties (printed by rl_destroy)
+    long long tie_regrown = 0;      // trees grown a second time because a deferred tie over several features hid two different cuts (k_tie_verify)
     long long tie_us = 0, tie_spec_segs = 0, tie_spec_miss = 0, tie_spec_serial = 0, tie_spec_repairs = 0;      // host time in resolve_ties; segments evaluated, window misses, serial segments, repair passes
     std::vector<int32_t> h_nthr; std::vector<char> tie_blob;
     void *tie_pin = nullptr; size_t tie_pin_cap = 0;                                          // pinned staging of its small device-to-host reads
@@ -463,7 +465,7 @@ static int tie_arena_reserve(rl_trainer *t, size_t bytes)
 // deferred = false: the tree is stalled on TreeState::stall_node (ties whose candidates may cut the node differently); afterwards the growth resumes.
 // deferred = true: the tree is grown; the committed nodes flagged 0x40 (plateau ties of right children: the partition was known, the stored
 // threshold was not) get the Java's threshold, all of them in one batch, before the tree is exported.
-static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool deferred = false)
+static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool deferred = false, bool *other_cut = nullptr)
 {
     Ctx &c = t->ctx;
     hipStream_t s = t->stream;
@@ -481,6 +483,10 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool de
     RL_HIP(hipMemcpyAsync(pin, c.st, sizeof(TreeState), hipMemcpyDeviceToHost, s));
     RL_HIP(hipMemcpyAsync(pin + sizeof(TreeState), c.nodes, (size_t)c.NC * sizeof(NodeRec), hipMemcpyDeviceToHost, s));
     RL_HIP(hipStreamSynchronize(s));
+    static const bool tie_prof = getenv("RLHIP_TIE_PROF") != nullptr;
+    auto t_last = t_begin;
+    auto mark = [&](int ph) { if (!tie_prof) return; const auto now = std::chrono::steady_clock::now(); t->tie_phase_us[ph] += (long long)std::chrono::duration_cast<std::chrono::microseconds>(now - t_last).count(); t_last = now; };
+    mark(0);
     TreeState st;
     memcpy(&st, pin, sizeof(st));
     if (!deferred && (st.stall_n <= 0 || st.stall_n > kSpec)) return fail(RL_ERR_STATE, "resolve_ties without a stalled tree (internal error)");
@@ -507,6 +513,23 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool de
         return (int)an.size() - 1;
     };
     const int nx = (int)todo.size();
+    // deferred ties over several features: the node was cut by its first candidate; that every tied candidate cuts it the same way is verified
+    // document by document (k_tie_verify) -- these are the nodes, with the split predicates of their paths
+    std::vector<TieNode> vn; std::vector<int32_t> vx;
+    if (deferred)
+        for (int x = 0; x < nx; x++) {
+            if ((nodes[todo[x]].tie & 3) != 2) continue;
+            TieNode V; memset(&V, 0, sizeof(V));
+            V.node = todo[x]; V.pred0 = (int)preds.size(); V.is_root = (todo[x] == 0) ? 1 : 0; V.gcount = nodes[todo[x]].gcount;
+            for (int ch = todo[x]; nodes[ch].parent >= 0; ch = nodes[ch].parent) {
+                const NodeRec &P = nodes[nodes[ch].parent];
+                preds.push_back(TiePred{P.best_f, P.best_t, P.pl == ch ? 1 : 0});
+                V.npred++;
+            }
+            vn.push_back(V); vx.push_back(x);
+        }
+    const int nv = (int)vn.size();
+    int32_t *d_vflag = nullptr;
     std::vector<std::vector<int>> chains((size_t)nx);
     size_t chain_cap = 1;
     for (int x = 0; x < nx; x++) {
@@ -538,9 +561,14 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool de
         for (size_t i = 0; i < chains[x].size(); i++) xchain[(size_t)x * chain_cap + i] = chains[x][i];
     }
     const int tiles = (c.N + kTieTile - 1) / kTieTile, nbg = (c.TS + 63) / 64;
+    // short chains: the literal walk (one kernel, ~6 ns a document) beats the dozen launches and two more host round trips of the contiguous-chain path;
+    // known before anything ran on the device, so stage 1 does not have to report back either
+    static const size_t walk_max = getenv("RLHIP_TIE_WALK_MAX") ? (size_t)atoll(getenv("RLHIP_TIE_WALK_MAX")) : (size_t)24576;
+    const bool walk_early = !sharded && (getenv("RLHIP_TIE_WALK") != nullptr || u_total <= walk_max || (size_t)kTsWaves * c.TS * 4 > (size_t)60 * 1024);
     // ---- stage 1: fixed-size scratch, the tied candidates, the member lists
     const size_t fixed_bytes = (size_t)nx * c.F * c.TS + ((size_t)nA * c.F + (size_t)nx * c.F + (size_t)nA * tiles + list_total + 64) * 4 + ((size_t)nA * c.F * c.TS + nA) * 8 +
-                               (xchain.size() + 2 * (size_t)nx + 16) * 4 + (size_t)nA * sizeof(TieNode) + (preds.size() + 1) * sizeof(TiePred) + (size_t)nA * 8 + 64 * 256;
+                               (xchain.size() + 2 * (size_t)nx + 16) * 4 + (size_t)nA * sizeof(TieNode) + (preds.size() + 1) * sizeof(TiePred) + (size_t)nA * 8 + 64 * 256 +
+                               (nv > 0 ? (size_t)nx * c.F * 12 + (size_t)nx * 4 + (size_t)nv * (sizeof(TieNode) + 4) + 1024 : 0) + (size_t)nx * c.F * 12 + 1024;
     if (tie_arena_reserve(t, std::max(fixed_bytes + ((size_t)64 << 20), t->tie_hint))) return fail(RL_ERR_HIP, "tie-break: out of device memory");
     TieArena ar;
     TieArgs a;
@@ -556,6 +584,7 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool de
         auto put = [&](const void *src, size_t bytes) { const size_t o = (blob.size() + 15) & ~(size_t)15; blob.resize(o + bytes); if (bytes) memcpy(blob.data() + o, src, bytes); return o; };
         const size_t o_xnode = put(xnode.data(), nx * sizeof(int32_t)), o_xlen = put(xlen.data(), nx * sizeof(int32_t)), o_xchain = put(xchain.data(), xchain.size() * sizeof(int32_t));
         const size_t o_an = put(an.data(), nA * sizeof(TieNode)), o_preds = put(preds.data(), preds.size() * sizeof(TiePred)), o_u0 = put(u0.data(), nA * sizeof(long long));
+        const size_t o_vn = put(vn.data(), nv * sizeof(TieNode)), o_vx = put(vx.data(), nv * sizeof(int32_t));
         char *d_blob = ar.take<char>(blob.size() + 16);
         RL_HIP(hipMemcpyAsync(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, s));
         int32_t *d_xnode = (int32_t *)(d_blob + o_xnode), *d_xlen = (int32_t *)(d_blob + o_xlen), *d_xchain = (int32_t *)(d_blob + o_xchain);
@@ -564,9 +593,16 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool de
         a.tmask = ar.take<uint8_t>((size_t)nx * c.F * c.TS); a.need = ar.take<int32_t>((size_t)nA * c.F); a.xf = ar.take<int32_t>((size_t)nx * c.F);
         a.tile_cnt = ar.take<int32_t>((size_t)nA * tiles); a.list = ar.take<int32_t>(list_total + 1);
         a.jbin = ar.take<double>((size_t)nA * c.F * c.TS); a.jtot = ar.take<double>(nA);
+        a.fS = ar.take<double>((size_t)nx * c.F); a.ft = ar.take<int32_t>((size_t)nx * c.F);
         RL_HIP(hipMemsetAsync(a.need, 0, (size_t)nA * c.F * sizeof(int32_t), s));
         a.xnode = d_xnode; a.xlen = d_xlen; a.xchain = d_xchain; a.preds = d_preds;
+        if (nv > 0) {
+            a.vcnt = ar.take<int32_t>((size_t)nx + 1); a.vlist = ar.take<int32_t>((size_t)nx * c.F * 3);
+            d_vflag = a.vcnt + nx;
+            RL_HIP(hipMemsetAsync(a.vcnt, 0, ((size_t)nx + 1) * sizeof(int32_t), s));
+        }
         hipLaunchKernelGGL(k_tie_cand, dim3(c.F, nx), dim3(kFinThreads), 0, s, c, a);
+        if (nv > 0) hipLaunchKernelGGL(k_tie_verify, dim3(tiles, nv), dim3(kThreads), 0, s, c, a, (const TieNode *)(d_blob + o_vn), (const int32_t *)(d_blob + o_vx), d_vflag);
         bool any_list = false;
         for (auto &A : an) any_list |= !A.is_root;
         if (any_list) {
@@ -574,6 +610,7 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool de
             hipLaunchKernelGGL(k_tie_scan, dim3(nA), dim3(kThreads), 0, s, a, tiles);
             hipLaunchKernelGGL(k_tie_scatter, dim3(tiles, nA), dim3(kThreads), 0, s, c, a, tiles);
         }
+        if (walk_early) return RL_OK;       // (need / lcnt stay zero: no pairs, the walk below)
         RL_HIP(hipMemcpyAsync(pin, a.need, need.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         RL_HIP(hipMemcpyAsync(pin + need.size() * sizeof(int32_t), a.an, (size_t)nA * sizeof(TieNode), hipMemcpyDeviceToHost, s));
         RL_HIP(hipStreamSynchronize(s));
@@ -584,7 +621,9 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool de
         }
         return RL_OK;
     };
+    mark(1);
     { int rc1 = stage1(); if (rc1) return rc1; }
+    mark(2);
     // ---- stage 2: the needed (chain node, feature) pairs, their bins' sizes, the chains and their segments
     std::vector<TiePair> pairs;
     size_t v_total = u_total, m_total = 0;
@@ -597,9 +636,7 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool de
                 pairs.push_back(P);
             }
     const int npairs = (int)pairs.size();
-    // short chains: the literal walk (one kernel, ~6 ns a document) beats the dozen launches and two more host round trips of the contiguous-chain path
-    static const size_t walk_max = getenv("RLHIP_TIE_WALK_MAX") ? (size_t)atoll(getenv("RLHIP_TIE_WALK_MAX")) : (size_t)24576;
-    bool walk = getenv("RLHIP_TIE_WALK") != nullptr || npairs == 0 || u_total <= walk_max || (size_t)kTsWaves * c.TS * 4 > (size_t)60 * 1024;      // (huge threshold tables: the sort's cursors would not fit the LDS)
+    bool walk = walk_early || npairs == 0 || (size_t)kTsWaves * c.TS * 4 > (size_t)60 * 1024;      // (huge threshold tables: the sort's cursors would not fit the LDS)
     if (sharded) walk = false;                // the walk reads this rank's documents only; rl_init keeps the tie-break off for sharded runs with huge tables
     std::vector<int32_t> cnts((size_t)npairs * c.TS);
     if (!walk) {       // cumulative bin counts of the pairs (exact): where every bin's run starts in the sorted values
@@ -750,10 +787,16 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool de
         }
         t->tie_spec_segs += nchunks;
     }
-    const size_t tf_lds = std::max(fin_lds, std::min((size_t)96 * 1024, (size_t)chain_cap * c.TS * 8));       // staging of a feature's chain arrays; select_step afterwards
-    hipLaunchKernelGGL(k_tie_finish, dim3(1), dim3(kFinThreads), tf_lds, s, c, a, nodes_in_lds, (int)tf_lds, deferred ? 1 : 0);
+    mark(3);
+    // prefixes of all needed rows at once, the tied candidates of all (feature, node) pairs at once, then one block: arg-max, node records, select_step
+    hipLaunchKernelGGL(k_tie_prefix, dim3(c.F, nA), dim3(64), (size_t)c.TS * 8, s, c, a);
+    hipLaunchKernelGGL(k_tie_eval, dim3(c.F, nx), dim3(kFinThreads), 0, s, c, a);
+    hipLaunchKernelGGL(k_tie_finish, dim3(1), dim3(kFinThreads), fin_lds, s, c, a, nodes_in_lds, deferred ? 1 : 0);
     RL_HIP(hipGetLastError());
+    if (nv > 0) RL_HIP(hipMemcpyAsync(pin, d_vflag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     RL_HIP(hipStreamSynchronize(s));
+    mark(4);
+    if (nv > 0 && other_cut) { int32_t fl = 0; memcpy(&fl, pin, sizeof(fl)); *other_cut = (fl != 0) || getenv("RLHIP_TIE_FORCE_REGROW") != nullptr; }
     t->tie_stalls++; t->tie_nodes += nx; t->tie_chain_nodes += nA; if (deferred) t->tie_batches++;
     for (auto &A : an) t->tie_chain_docs += A.count;
     t->tie_us += (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_begin).count();
@@ -819,6 +862,11 @@ static int enqueue_round(rl_trainer *t)
     const size_t red_lds = (size_t)c.TS * 20;
     const int rootCs = std::min(kChunk, std::max(kMinChunk, (((c.N + 63) / 64 + 255) & ~255)));   // == chunk_docs<true>(N)
     const int rootChunks = (c.N + rootCs - 1) / rootCs;
+    // (a tree is grown a second time, from its root histogram, when the deferred tie-break finds that a tie over several features it took for one
+    // cut is not one -- rl_tie.inc, k_tie_verify; nothing a round keeps has been written by then)
+    const int tie_mode = c.tie_on;
+    struct TieModeRestore { Ctx &c; int v; ~TieModeRestore() { c.tie_on = v; } } tie_mode_restore{c, tie_mode};
+  regrow:
     {   // K2 root histogram: dense groups from their 32-byte rows, groups of sparse columns from their entry lists (rl_csc.inc)
         const double root_bytes = c.sp_on ? (double)c.N * ((double)(c.numFG - c.sp_ngroups) * kHistFG * 2.0 + 8.0) + (double)t->sp_entries * 4.0
                                           : (double)c.N * ((double)c.F * 2.0 + 8.0);
@@ -861,6 +909,14 @@ static int enqueue_round(rl_trainer *t)
         int rcs = resolve_ties(t, fin_lds, nodes_in_lds);
         if (rcs) return rcs;
         extra += 2;
+        if (c.progress) {       // resolve_ties waited for k_tie_finish, whose select_step left (step, done, deferred ties) in the pinned progress word
+            const unsigned long long w = __atomic_load_n(t->h_progress, __ATOMIC_ACQUIRE);
+            if ((w >> 32) != t->tree_seq) return fail(RL_ERR_STATE, "tie-break: the progress word is not this tree's (internal error)");
+            ended = (w & 1ull) != 0;
+            if (ended) defer_seen = ((w >> 30) & 1ull) != 0;
+            it = (int)((unsigned)(w & 0x3fffffffull) >> 1);
+            return RL_OK;
+        }
         TreeState sth;
         RL_HIP(hipMemcpy(&sth, c.st, sizeof(sth), hipMemcpyDeviceToHost));
         ended = sth.done != 0;
@@ -872,8 +928,7 @@ static int enqueue_round(rl_trainer *t)
     for (; it < steps + extra; it++) {
         if (throttle && c.tie_on && !t->dist) {
             const unsigned long long w0 = __atomic_load_n(t->h_progress, __ATOMIC_ACQUIRE);
-            if (stalled(w0)) {
-                RL_HIP(hipStreamSynchronize(s));
+            if (stalled(w0)) {       // (resolve_ties reads the tree state through the stream: no drain of its own needed here)
                 bool ended = false;
                 int rcs = after_stall(ended);
                 if (rcs) return rcs;
@@ -912,7 +967,6 @@ static int enqueue_round(rl_trainer *t)
                 // a stalled tree (rl_tie.inc): the word keeps the step at which it stalled, so -- as for the end of the tree -- every rank acts on
                 // it at the same `it`, after the same number of (empty) steps and their collectives
                 if (stalled(w) && step_w <= it - t->step_ahead) {
-                    RL_HIP(hipStreamSynchronize(s));
                     bool ended = false;
                     int rcs = after_stall(ended);
                     if (rcs) return rcs;
@@ -1058,14 +1112,16 @@ static int enqueue_round(rl_trainer *t)
         enqueue_chain(t, t->leaf_chain, src);
         hipLaunchKernelGGL(k_leaf_output, dim3((c.L + kThreads - 1) / kThreads), dim3(kThreads), 0, s, c, t->leaf_chain);
     }
-    hipLaunchKernelGGL(k_score_update, dim3(std::min(4096, (c.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, c);
     if (c.tie_on && defer_seen) {
-        // plateau ties of right children: the tree was grown with the partitions they all share; the thresholds the Java's rounding noise would
-        // store are decided now, in one batch (the leaf sums and the score update above are already enqueued and run meanwhile)
-        RL_HIP(hipStreamSynchronize(s));
-        int rcs = resolve_ties(t, fin_lds, nodes_in_lds, true);
+        // deferred ties (plateaus of right children, several features over one cut): the tree was grown with the partition the tied candidates
+        // share; the (feature, threshold) the Java's rounding noise would store is decided now, in one batch (the leaf sums above are already
+        // enqueued and run meanwhile; the score update waits, because a tie that turns out to hide two different cuts restarts the tree)
+        bool other_cut = false;
+        int rcs = resolve_ties(t, fin_lds, nodes_in_lds, true, &other_cut);
         if (rcs) return rcs;
+        if (other_cut && (c.tie_on & 2)) { c.tie_on = 1; t->tie_regrown++; goto regrow; }
     }
+    hipLaunchKernelGGL(k_score_update, dim3(std::min(4096, (c.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, c);
     hipLaunchKernelGGL(k_export_tree, dim3(1), dim3(kThreads), 0, s, c, t->ens, m);
     RL_HIP(hipGetLastError());
     // per-round training metric (LambdaMART.java:216)
@@ -1300,6 +1356,9 @@ void rl_destroy(rl_trainer *t)
 {
     if (!t) return;
     (void)hipSetDevice(t->p.device);
+    if (getenv("RLHIP_TIE_PROF") && t->tie_stalls > 0)
+        fprintf(stderr, "[rlhip] tie-break: %lld resolutions (%lld batches, %lld trees regrown), host us: first read %lld, chains %lld, candidates+lists %lld, sums %lld, finish %lld, total %lld\n",
+                t->tie_stalls, t->tie_batches, t->tie_regrown, t->tie_phase_us[0], t->tie_phase_us[1], t->tie_phase_us[2], t->tie_phase_us[3], t->tie_phase_us[4], t->tie_us);
     if (t->stream) { (void)hipStreamSynchronize(t->stream); }
     if (t->side) { (void)hipStreamSynchronize(t->side); (void)hipStreamDestroy(t->side); }
     if (t->ev_ranked) (void)hipEventDestroy(t->ev_ranked);
@@ -1491,6 +1550,9 @@ int rl_init(rl_trainer *t)
     // sharded runs evaluate the tie-break on gathered arrays through the contiguous-chain path only: with threshold tables too large for its sort
     // (the literal walk reads one rank's documents) they keep the first candidate.  TS is the same on every rank, so is the decision.
     if (t->dist && t->n_ranks > 1 && (size_t)kTsWaves * TS * 4 > (size_t)60 * 1024) c.tie_on = 0;
+    // bit 1: ties over several features that all cut a node the same way are deferred to the end of the tree like plateau ties (one GPU: the check
+    // that it IS one cut reads the node's documents, rl_tie.inc k_tie_verify)
+    if (c.tie_on && !(t->dist && t->n_ranks > 1) && !getenv("RLHIP_TIE_NO_XDEFER")) c.tie_on |= 2;
     if (t->p.n_leaves == -1) {      // -leaf -1: the node histograms are sized for floor(N / mls) leaves -- say so before an allocation fails
         const double need = (double)c.NC * F * TS * ((t->p.flags & RL_FLAG_JAVA_ORDER) ? 28.0 : 20.0);
         size_t mem_free = 0, mem_total = 0;
@@ -2159,7 +2221,8 @@ int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes)
         return RL_OK;
     }
     case RL_ARR_TIE_STATS: {
-        const int64_t v[8] = {t->tie_stalls, t->tie_nodes, t->tie_chain_nodes, t->tie_chain_docs, t->tie_us, t->tie_spec_segs, t->tie_spec_miss, t->tie_spec_serial};
+        const int64_t v[10] = {t->tie_stalls, t->tie_nodes, t->tie_chain_nodes, t->tie_chain_docs, t->tie_us, t->tie_spec_segs, t->tie_spec_miss, t->tie_spec_serial,
+                                t->tie_batches, t->tie_regrown};
         if (cap_bytes < (int64_t)sizeof(v)) return fail(RL_ERR_INVALID, "output buffer too small");
         memcpy(out, v, sizeof(v));
         return RL_OK;

@@ -1,0 +1,3 @@
+import json,sys
+d=json.loads(sys.stdin.read()); tb=d["config"]["tie_break"]
+print(sys.argv[1], round(d["value"],1), round(d["config"].get("sustained_rounds_per_s",0),1), tb["resolutions"], tb["nodes"], tb["chain_documents"], round(tb["host_ms"],1))

@@ -54,10 +54,13 @@ def main():
           "%d speculative segments, %d window misses, %d serial segments" % (int(ts[0]), int(ts[1]), int(ts[2]), int(ts[3]), ts[4] / 1e3, int(ts[5]), int(ts[6]), int(ts[7])))
     print("committed splits with a tied best candidate: %d in %d rounds (%.2f per round)" % (len(ties), trees, len(ties) / max(trees, 1)))
     if len(ties):
+        same_cut = np.sum(((ties[:, 2] & 3) == 2) & ((ties[:, 2] & 4) != 0))      # several features, one cut (deferred to the end of the tree)
+        ties = ties.copy(); ties[:, 2] &= 3
         need = ties[(ties[:, 2] == 2) | ((ties[:, 3] & 1) == 1)]
         print("  tie kinds: %d plateaus of one feature (%d of them in right children), %d across features (lanes of 32 holding a tied feature: median %d max %d)" %
               (np.sum(ties[:, 2] == 1), np.sum((ties[:, 2] == 1) & ((ties[:, 3] & 1) == 1)), np.sum(ties[:, 2] == 2),
                np.median(ties[ties[:, 2] == 2, 3] >> 1) if np.any(ties[:, 2] == 2) else 0, (ties[ties[:, 2] == 2, 3] >> 1).max() if np.any(ties[:, 2] == 2) else 0))
+        print("  across features with every tied candidate cutting off the same (count, exact sum): %d" % same_cut)
         print("  of those the Java's noise decides (several features tie, or a plateau in a right child): %d (%.2f per round)" % (len(need), len(need) / trees))
         for name, col in (("documents of the node", 4), ("largest node of the derivation chain", 5), ("nodes in the chain", 6), ("documents in the chain", 7)):
             if len(need):
