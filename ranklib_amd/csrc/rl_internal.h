@@ -38,6 +38,10 @@ constexpr int kHistLdsBytes = 64 * 1024;
 constexpr int kSpec = RL_KSPEC;      // nodes split (speculatively, in queue order) per growth step
 constexpr int kLambdaWaveCap = 384;  // docs/query handled by the wave-per-query lambda kernel
 constexpr int kLambdaBlockCap = 5000;
+#ifndef RL_RANK_SHORT
+#define RL_RANK_SHORT 384
+#endif
+constexpr int kRankShort = RL_RANK_SHORT;      // lists up to this length get a launch of k_rank_wave with less LDS per wavefront (more wavefronts per CU)
 constexpr int kLambdaFusedMaxK = 16;  // NDCG@k up to this k uses the LDS-resident fused lambda kernel
 
 // A tree node while the tree is being grown (device resident).

@@ -60,7 +60,7 @@ struct DataSet {
     int32_t *d_aux_i = nullptr; double *d_aux_a = nullptr, *d_aux_b = nullptr;   // swapChange tables of MAP / ERR in ranked order
     // -qrel (rl_set_external_judgments): per list, the idealGains entry of its qid in the judgment file (NaN = none) and its relDocCount
     std::vector<double> ext_ideal; std::vector<int32_t> ext_rd; int32_t *d_ext_rd = nullptr;
-    int32_t *d_qsmall = nullptr, *d_qbig = nullptr, *d_qtiny = nullptr; int32_t n_small = 0, n_big = 0, n_tiny = 0; bool all_small = false;
+    int32_t *d_qsmall = nullptr, *d_qbig = nullptr, *d_qtiny = nullptr; int32_t n_small = 0, n_big = 0, n_tiny = 0, max_big = 0, n_small_long = 0; bool all_small = false;
     int32_t *d_qhuge = nullptr, *d_relscratch = nullptr; int32_t n_huge = 0;      // lists beyond kLambdaBlockCap documents (k_rank_huge)
     // queries by length class for the fused lambda kernel: <= 64, <= 128, <= 192 documents, longer (tiled by 256); a block is as
     // wide as its class, so short lists do not leave most of a block idle
@@ -220,6 +220,9 @@ static int upload_query_side(rl_trainer *t, DataSet &d, const std::vector<double
     std::stable_sort(small.begin(), small.end(), by_len);
     std::stable_sort(big.begin(), big.end(), by_len);
     d.n_small = (int32_t)small.size(); d.n_big = (int32_t)big.size();
+    d.n_small_long = 0;
+    for (int32_t q : small) d.n_small_long += (d.qoff[q + 1] - d.qoff[q] > kRankShort) ? 1 : 0;
+    d.max_big = big.empty() ? 0 : (((d.qoff[big[0] + 1] - d.qoff[big[0]]) + 63) & ~63);      // (longest first) what k_rank_block's LDS is sized for
     d.all_small = false;      // the lists are permutations now: always index through them
     RL_HIP(t->pool.alloc(&d.d_qsmall, small.size()));
     RL_HIP(t->pool.alloc(&d.d_qbig, big.size()));
@@ -396,11 +399,25 @@ static int launch_rank(rl_trainer *t, DataSet &d, const double *scores, double *
     if (d.n_tiny > 0)
         hipLaunchKernelGGL(k_rank_tiny, dim3((d.n_tiny + kRankTinyGroups - 1) / kRankTinyGroups), dim3(kRankTinyDocs * kRankTinyGroups), 0, t->stream, a,
                            (const int *)d.d_qtiny, d.n_tiny);
-    if (d.n_small > 0)
-        hipLaunchKernelGGL(k_rank_wave, dim3((d.n_small + 3) / 4), dim3(kThreads), 4 * kLambdaWaveCap * 12, t->stream, a,
-                           d.all_small ? (const int *)nullptr : d.d_qsmall, d.n_small);
+    static const bool rank_mixed = getenv("RLHIP_RANK_SPLIT") == nullptr;
+    if (rank_mixed && d.n_big > 0 && d.n_small > 0) {
+        const int wpb = kRankBlockThreads / 64;
+        const size_t lds = std::max((size_t)d.max_big, (size_t)wpb * kLambdaWaveCap) * kRankLdsPerDoc;
+        hipLaunchKernelGGL(k_rank_mixed, dim3(d.n_big + (d.n_small + wpb - 1) / wpb), dim3(kRankBlockThreads), lds, t->stream, a, (const int *)d.d_qbig, d.n_big, d.max_big,
+                           (const int *)d.d_qsmall, d.n_small, kLambdaWaveCap);
+        if (d.n_huge > 0)
+            hipLaunchKernelGGL(k_rank_huge, dim3(d.n_huge), dim3(kRankBlockThreads), 0, t->stream, a, (const int *)d.d_qhuge, d.n_huge, d.d_relscratch);
+        RL_HIP(hipGetLastError());
+        return RL_OK;
+    }
+    if (d.n_small_long > 0)       // (d_qsmall: longest first)
+        hipLaunchKernelGGL(k_rank_wave, dim3((d.n_small_long + 3) / 4), dim3(kThreads), 4 * kLambdaWaveCap * kRankLdsPerDoc, t->stream, a,
+                           (const int *)d.d_qsmall, d.n_small_long, kLambdaWaveCap);
+    if (d.n_small > d.n_small_long)
+        hipLaunchKernelGGL(k_rank_wave, dim3((d.n_small - d.n_small_long + 3) / 4), dim3(kThreads), 4 * kRankShort * kRankLdsPerDoc, t->stream, a,
+                           (const int *)d.d_qsmall + d.n_small_long, d.n_small - d.n_small_long, kRankShort);
     if (d.n_big > 0)
-        hipLaunchKernelGGL(k_rank_block, dim3(d.n_big), dim3(kRankBlockThreads), kLambdaBlockCap * 12, t->stream, a, d.d_qbig, d.n_big);
+        hipLaunchKernelGGL(k_rank_block, dim3(d.n_big), dim3(kRankBlockThreads), (size_t)d.max_big * kRankLdsPerDoc, t->stream, a, d.d_qbig, d.n_big, d.max_big);
     if (d.n_huge > 0)
         hipLaunchKernelGGL(k_rank_huge, dim3(d.n_huge), dim3(kRankBlockThreads), 0, t->stream, a, (const int *)d.d_qhuge, d.n_huge, d.d_relscratch);
     RL_HIP(hipGetLastError());
@@ -1341,7 +1358,8 @@ int rl_create(const rl_params *p, rl_trainer **out)
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    RL_HIP(hipFuncSetAttribute((const void *)k_rank_block, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaBlockCap * 12));
+    RL_HIP(hipFuncSetAttribute((const void *)k_rank_block, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaBlockCap * kRankLdsPerDoc));
+    RL_HIP(hipFuncSetAttribute((const void *)k_rank_mixed, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(kLambdaBlockCap, (kRankBlockThreads / 64) * kLambdaWaveCap) * kRankLdsPerDoc));
     RL_HIP(hipFuncSetAttribute((const void *)k_lambda_tiny, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaTinyGroups * lambda_tiny_group_bytes(kLambdaFusedMaxK)));
     RL_HIP(hipFuncSetAttribute((const void *)k_lambda_fused<256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaFusedMaxK * (256 + 8) * 16 + 2048));
     RL_HIP(hipFuncSetAttribute((const void *)k_lambda_fused<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaFusedMaxK * (256 + 8) * 16 + 8192));
