@@ -96,3 +96,65 @@ def test_huge_threshold_tables_take_the_walk():
         assert assert_equivalent(to, tg, X, "round %d" % r) == 0
     st = g.array("TIE_STATS")
     assert st[0] > 0 and st[5] == 0, st
+
+
+def duplicate_columns(seed, n_docs=6000, n_feat=8):
+    """columns 4.. repeat columns 0..3 (scaled: other thresholds, the same cuts): ties over several features whose candidates all cut a node the same way"""
+    X, lab, qoff = synth.make_dataset(n_docs, n_feat, "mslr", seed_offset=seed)
+    X = X.copy()
+    for j in range(4, n_feat):
+        X[:, j] = 2.0 * X[:, j - 4] + 1.0
+    return X, lab, qoff
+
+
+def test_ties_over_several_features_that_share_one_cut_are_deferred_not_stalled(monkeypatch):
+    """duplicated columns: every best split ties across two features over one and the same cut.  The tree is not stalled on them: they join the per-tree
+    batch (k_tie_verify checks the cuts document by document), the oracle's feature is stored, and the switch that stalls on them instead gives the
+    same trees with many more resolutions"""
+    X, lab, qoff = duplicate_columns(31)
+    trees, ties, st, sc = run(X, lab, qoff, 5, 31)
+    assert ties == 0
+    assert st[8] > 0 and st[9] == 0, st                                # batches at the end of trees, no tree grown twice
+    assert st[1] > 5 * st[0], st                                       # dozens of nodes per batch
+    monkeypatch.setenv("RLHIP_TIE_NO_XDEFER", "1")
+    trees_s, ties_s, st_s, sc_s = run(X, lab, qoff, 5, 31)
+    assert ties_s == 0 and st_s[0] > 3 * st[0], (st, st_s)
+    same_trees(trees, trees_s)
+    assert np.array_equal(sc.view(np.int64), sc_s.view(np.int64))
+
+
+def test_a_tree_whose_deferred_tie_fails_the_check_is_grown_again(monkeypatch):
+    """the verification's miss path, forced: every batch with a tie over several features reports another cut, the tree is grown again from its root
+    histogram with the shortcut off (stalls instead) -- same trees, same scores, the counter says how often"""
+    X, lab, qoff = duplicate_columns(32)
+    trees, ties, st, sc = run(X, lab, qoff, 4, 24)
+    assert ties == 0 and st[9] == 0
+    monkeypatch.setenv("RLHIP_TIE_FORCE_REGROW", "1")
+    trees_r, ties_r, st_r, sc_r = run(X, lab, qoff, 4, 24)
+    assert ties_r == 0 and st_r[9] > 0, st_r
+    same_trees(trees, trees_r)
+    assert np.array_equal(sc.view(np.int64), sc_r.view(np.int64))
+
+
+def test_equal_lambdas_on_opposite_sides_are_caught_by_the_check():
+    """two candidates of two features with equal (left count, exact left sum) that are NOT the same documents: lists whose documents all carry one label
+    have lambda = 0, and two such documents swapped between the sides leave count and sum unchanged.  Built on purpose: feature 0 takes two values and
+    carries the labels, feature 1 repeats it with two zero-lambda documents swapped -- the root's best split ties over the two features with
+    different cuts.  The device defers it (equal keys), the check finds the two documents, the tree is grown again with a stall, and the stored trees
+    are the oracle's"""
+    rng = np.random.default_rng(5)
+    n_q, per = 60, 20
+    n = n_q * per
+    qoff = np.arange(0, n + 1, per, dtype=np.int32)
+    right = rng.random(n) < 0.5
+    lab = np.where(right, rng.integers(1, 4, n), rng.integers(0, 2, n)).astype(np.float32)
+    lab[:2 * per] = 1.0                                               # two single-label lists: every lambda in them is exactly 0
+    a, b = 3, per + 5
+    right[a], right[b] = False, True
+    X = (rng.standard_normal((n, 4)) * 0.01).astype(np.float32)
+    X[:, 0] = np.where(right, -0.75, -2.0)
+    X[:, 1] = X[:, 0]
+    X[a, 1], X[b, 1] = X[b, 0], X[a, 0]                               # the copy disagrees on the two zero-lambda documents
+    trees, ties, st, _ = run(X, lab, qoff, 3, 8)
+    assert ties == 0, st
+    assert st[9] > 0, st                                              # at least the first tree was grown twice
