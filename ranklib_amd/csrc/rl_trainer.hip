@@ -98,6 +98,7 @@ struct rl_trainer {
     int32_t synced_rounds = 0;
     long long tie_stalls = 0, tie_nodes = 0, tie_chain_nodes = 0, tie_chain_docs = 0;      // lazy tie-break (rl_tie.inc): resolutions run, nodes resolved, chain nodes / documents summed
     long long tie_batches = 0;      // of the resolutions, the batched ones at the end of a tree (deferred ties)
+    bool fin_split = false;      // wide data: k_hist_finish_wide + k_select instead of the fused finish (rl_init)
     long long tie_phase_us[6] = {0, 0, 0, 0, 0, 0};   // RLHIP_TIE_PROF: host microseconds per phase of resolve_ties (printed by rl_destroy)
     long long tie_regrown = 0;      // trees grown a second time because a deferred tie over several features hid two different cuts (k_tie_verify)
     long long tie_us = 0, tie_spec_segs = 0, tie_spec_miss = 0, tie_spec_serial = 0, tie_spec_repairs = 0;      // host time in resolve_ties; segments evaluated, window misses, serial segments, repair passes
@@ -1046,6 +1047,9 @@ static int enqueue_round(rl_trainer *t)
             if (c.jmap) hipLaunchKernelGGL(k_jhist2, dim3(c.n_live + 1, kSpec), dim3(kJ2Threads), 0, s, c, 0, c.jmap, c.jinv, c.jone);
             else hipLaunchKernelGGL(k_jhist, dim3(c.n_live, jbg + 2, kSpec), dim3(64), 0, s, c, 0, jbg);
             hipLaunchKernelGGL((k_hist_finish<false, false, true>), dim3(c.n_live, kSpec), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
+        } else if (t->fin_split) {
+            hipLaunchKernelGGL(k_hist_finish_wide, dim3(c.n_live, kSpec), dim3(kFinThreads), (size_t)c.TS * 20 + 8, s, c);
+            hipLaunchKernelGGL(k_select, dim3(1), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
         } else hipLaunchKernelGGL((k_hist_finish<false, false>), dim3(c.n_live, kSpec), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
     }
     if (c.tie_on && !saw_end) {
@@ -1352,6 +1356,8 @@ int rl_create(const rl_params *p, rl_trainer **out)
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * 20));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_sp<kHistLdsStride>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistFG * kHistLdsStride * 8));
+    RL_HIP(hipFuncSetAttribute((const void *)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish_wide, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -1563,6 +1569,13 @@ int rl_init(rl_trainer *t)
         RL_HIP(t->pool.alloc(&d_live, live.size()));
         RL_HIP(hipMemcpy(d_live, live.data(), live.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         c.live = d_live; c.n_live = (int32_t)live.size();
+    }
+    {   // more finish blocks a step than the fused kernel keeps resident (5 a CU): the per-feature work and the bookkeeping become two launches
+        const char *e = getenv("RLHIP_FIN_SPLIT");
+        int n_cu = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, t->p.device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+        t->fin_split = !t->dist && !(t->p.flags & RL_FLAG_JAVA_ORDER) && (e ? atoi(e) != 0 : (long long)c.n_live * kSpec > 5ll * n_cu);
     }
     if ((size_t)TS * 12 > (size_t)kHistLdsBytes) return fail(RL_ERR_UNSUPPORTED, "too many threshold candidates for the LDS histogram");
     // sharded runs evaluate the tie-break on gathered arrays through the contiguous-chain path only: with threshold tables too large for its sort
