@@ -1485,7 +1485,9 @@ int rl_init(rl_trainer *t)
     c.MAXN = std::max(2 * L_eff - 1, 3);
     c.NC = 4 * L_eff + 2;     // node records: committed (2L-1) + prepared but never reached (see select_step)
     c.mls = t->p.min_leaf_support; c.lr = t->p.learning_rate;
-    c.node_div = 12; c.node_min = kMinChunk;
+    // chunks a child node is cut into: every chunk flushes a partial histogram of F x T x 12 bytes that the finish reads back, so wide data wants fewer
+    // (measured, rounds/s: c3, 700 columns: 3 / 4 / 6 / 8 / 12 / 16 / 24 -> 542 / 548 / 548 / 549-556 / 534 / 537 / 513; c2, 136 columns: flat from 8 to 32)
+    c.node_div = std::max(4, std::min(12, (int)(12.0 * std::sqrt(136.0 / (double)std::max(F, 1)) + 0.5))); c.node_min = kMinChunk;
     c.fs_size = F; c.seed = t->p.seed;
     if (t->p.feature_sampling_rate > 0.0f && t->p.feature_sampling_rate < 1.0f) c.fs_size = (int32_t)(t->p.feature_sampling_rate * (float)F);   // :274
     if (const char *e = getenv("RLHIP_NODE_DIV")) c.node_div = std::max(1, atoi(e));          // tuning knobs (tools/), not API
