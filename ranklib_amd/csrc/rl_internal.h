@@ -106,7 +106,7 @@ struct Ctx {
     float lr;
     int32_t rank, n_ranks;
     int32_t Nglobal;              // documents over ALL ranks (== N on one GPU): fixes the lambda^2 exponent, which every rank must share
-    int32_t node_div, node_min;   // child-node histograms: target chunks per node, smallest chunk (see chunk_docs)
+    int32_t node_div, node_min, node_chunk;   // child-node histograms: target chunks per node, smallest / largest chunk (see chunk_docs)
     int32_t n_live; const int32_t *live;   // unsharded runs: features with more than one distinct value (the others can never split); k_hist_finish
                                   // is launched over these only (a third of the Yahoo-shape columns are empty)
     int32_t limb_words;           // sharded runs: int64 words per bin in the all-reduced histogram: 3 = (sum >> 44, sum & (2^44-1), count),

@@ -1492,6 +1492,10 @@ int rl_init(rl_trainer *t)
     if (t->p.feature_sampling_rate > 0.0f && t->p.feature_sampling_rate < 1.0f) c.fs_size = (int32_t)(t->p.feature_sampling_rate * (float)F);   // :274
     if (const char *e = getenv("RLHIP_NODE_DIV")) c.node_div = std::max(1, atoi(e));          // tuning knobs (tools/), not API
     if (const char *e = getenv("RLHIP_NODE_MIN")) c.node_min = std::max(256, atoi(e) & ~255);
+    // largest chunk: smaller ones spread a mid-sized node over more blocks (measured, same box: c1, 1.2 M x 136: 4096 -> +0.9 % / +1.6 % sustained; c2, 3.77 M: -0.7 %;
+    // c3, 700 columns: -1.8 %: every chunk more is another partial histogram of F x T x 12 bytes)
+    c.node_chunk = (N <= (2 << 20) && F <= 256) ? 4096 : kNodeChunk;
+    if (const char *e = getenv("RLHIP_NODE_CHUNK")) c.node_chunk = std::min(kNodeChunk, std::max(1024, atoi(e) & ~255));
     c.metric = t->p.metric; c.mart = (t->p.ranker == RL_RANKER_MART) ? 1 : 0;
     // lazy Java-order tie-break (rl_tie.inc): the default path's exact ties resolved as the Java's summation order resolves them.  Not with
     // feature sampling (the Java's draw is unseeded: nothing to match), not sharded (the Java's order is ONE sequence over all documents), not in
@@ -1606,7 +1610,7 @@ int rl_init(rl_trainer *t)
     RL_HIP(hipMemsetAsync(d_gbins, 0, (size_t)c.numFG * Npad * kHistFG * sizeof(uint16_t), s));
     c.bins = d_bins; c.gbins = d_gbins;
     // chunks of one growth step (all slots; see prepare_children), and of the root pass
-    c.maxChunks = N / kNodeChunk + 67 * kSpec + 2;
+    c.maxChunks = N / c.node_chunk + 67 * kSpec + 2;
     c.nTiles = (N + kPartTile - 1) / kPartTile + kSpec;      // tiles of one growth step (disjoint nodes, one ragged tile each)
     RL_HIP(t->pool.alloc(&c.cum_hi, (size_t)c.NC * F * TS));
     RL_HIP(t->pool.alloc(&c.cum_lo, (size_t)c.NC * F * TS));
