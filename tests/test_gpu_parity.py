@@ -953,3 +953,23 @@ def test_wide_and_deep_shapes_match_the_oracle(F, n, leaves):
         assert_equivalent(to, tg, X, "round %d" % r)
         assert np.array_equal(g.array("SCORE").view(np.int64), o.scores().view(np.int64)), r
         assert np.float32(tmg).view(np.uint32) == np.float32(tmo).view(np.uint32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_fused_and_two_launch_finish_give_the_same_trees(split, monkeypatch):
+    """the finish of a growth step is one launch (the last block runs the bookkeeping) or, on wide data, two (k_hist_finish_wide + k_select,
+    DESIGN.md 4.10); RLHIP_FIN_SPLIT forces either on any data.  Both against the oracle, with a validation set, on data whose trees need ties
+    resolved (the stalled / deferred paths re-enter the bookkeeping from another kernel)"""
+    monkeypatch.setenv("RLHIP_FIN_SPLIT", split)
+    X, lab, qoff = make(5000, 24, "mslr", 77)
+    Xv, lv, qv = make(1500, 24, "mslr", 78)
+    o, g = pair(X, lab, qoff, n_trees=6, n_leaves=20)
+    o.set_validation(Xv, lv, qv); g.set_validation(Xv, lv, qv)
+    o.init(); g.init()
+    for r in range(6):
+        to, tmo, vmo, _ = o.round()
+        tg, tmg, vmg, _ = g.boost_round()
+        assert_same_tree(to, tg, X, "round %d" % r)
+        assert np.float32(tmo).view(np.uint32) == np.float32(tmg).view(np.uint32)
+        assert np.float32(vmo).view(np.uint32) == np.float32(vmg).view(np.uint32)
