@@ -313,6 +313,8 @@ static int alloc_chain(rl_trainer *t, ChainBufs &b, int maxseg, int A, int64_t n
     RL_HIP(t->pool.alloc(&b.result, (size_t)A * maxseg)); RL_HIP(t->pool.alloc(&b.miss, (size_t)A * maxseg));
     RL_HIP(t->pool.alloc(&b.st_status, (size_t)A * maxseg)); RL_HIP(t->pool.alloc(&b.st_chunk, (size_t)A * maxseg));
     RL_HIP(t->pool.alloc(&b.st_key, (size_t)A * maxseg)); RL_HIP(t->pool.alloc(&b.st_delta, (size_t)A * maxseg));
+    RL_HIP(t->pool.alloc(&b.st_win, (size_t)A * maxseg));
+    b.lds_words = (int32_t)(chain_stitch_lds(b) / 4);
     RL_HIP(hipMemset(b.st_status, 0, (size_t)A * maxseg * sizeof(int32_t)));
     RL_HIP(hipMemset(b.miss, 0, (size_t)A * maxseg * sizeof(int32_t)));
     RL_HIP(t->pool.alloc(&b.arrive, (size_t)1)); RL_HIP(hipMemset(b.arrive, 0, sizeof(unsigned long long)));
@@ -360,19 +362,19 @@ static void enqueue_chain(rl_trainer *t, const ChainBufs &b, const ChainSource &
     const unsigned long long seq = ++t->chain_seq;
     bool hint = b.h_progress != nullptr && t->step_ahead > 0, clean = false;
     hipLaunchKernelGGL(k_chain_tables<false>, tgrid, dim3(kThreads), 0, s, b, 0);
-    hipLaunchKernelGGL(k_chain_stitch, dim3(b.maxseg, b.A), dim3(kScanThreads), lds, s, b, 0, seq << 8);
+    hipLaunchKernelGGL(k_chain_stitch, dim3(b.maxseg, b.A), dim3(kScanThreads), lds, s, b, 0, seq << 16);
     // With the hint the host sees every pass's outcome two passes later, so it can keep repairing for as long as a segment is open
     // (a chain of tens of millions of elements can meet more than kChainRepairs window misses; each pass costs two short launches, the
     // serial finish of a chain that long costs 100 ms); without it exactly kChainRepairs passes are enqueued blindly.
     for (int rep = 0; rep < (hint ? kChainRepairsMax : kChainRepairs); rep++) {
         if (hint && rep >= 1) {
-            const unsigned long long want = (seq << 8) | (unsigned)(rep - 1);      // stitch of repair pass rep-2 (0 = the first stitch)
+            const unsigned long long want = (seq << 16) | (unsigned)(rep - 1);      // stitch of repair pass rep-2 (0 = the first stitch)
             unsigned long long w;
             if (!spin_until(b.h_progress, [&](unsigned long long v) { return (v >> 1) >= want; }, w)) hint = false;
-            else if ((w >> 9) == seq && !(w & 1)) { clean = true; break; }
+            else if ((w >> 17) == seq && !(w & 1)) { clean = true; break; }
         }
-        hipLaunchKernelGGL(k_chain_tables<true>, tgrid, dim3(kThreads), 0, s, b, rep & 1);
-        hipLaunchKernelGGL(k_chain_stitch, dim3(b.maxseg, b.A), dim3(kScanThreads), lds, s, b, (rep & 1) ^ 1, (seq << 8) | (unsigned)(rep + 1));
+        hipLaunchKernelGGL(k_chain_tables<true>, tgrid, dim3(kThreads), 0, s, b, 1);
+        hipLaunchKernelGGL(k_chain_stitch, dim3(b.maxseg, b.A), dim3(kScanThreads), lds, s, b, 1, (seq << 16) | (unsigned)(rep + 1));
     }
     if (!clean) hipLaunchKernelGGL(k_chain_fallback, dim3(b.maxseg, b.A), dim3(64), 0, s, b);
 }
