@@ -308,6 +308,7 @@ static int alloc_chain(rl_trainer *t, ChainBufs &b, int maxseg, int A, int64_t n
     RL_HIP(t->pool.alloc(&b.tile_tot, (size_t)A * b.cap_tiles)); RL_HIP(t->pool.alloc(&b.tile_base, (size_t)A * b.cap_tiles));
     RL_HIP(t->pool.alloc(&b.bnd, (size_t)A * b.cap_tiles));
     RL_HIP(t->pool.alloc(&b.cbase, (size_t)A * b.cap_chunks)); RL_HIP(t->pool.alloc(&b.drift, (size_t)A * b.cap_chunks));
+    RL_HIP(t->pool.alloc(&b.drift2, (size_t)A * b.cap_chunks));
     RL_HIP(t->pool.alloc(&b.gkey, (size_t)A * b.cap_chunks)); RL_HIP(t->pool.alloc(&b.gkey2, (size_t)A * b.cap_chunks));
     RL_HIP(t->pool.alloc(&b.R, (size_t)A * b.cap_chunks * kChainW));
     RL_HIP(t->pool.alloc(&b.result, (size_t)A * maxseg)); RL_HIP(t->pool.alloc(&b.miss, (size_t)A * maxseg));
@@ -353,7 +354,8 @@ static void enqueue_chain(rl_trainer *t, const ChainBufs &b, const ChainSource &
     hipLaunchKernelGGL(k_chain_prefix, dim3(tb), dim3(kThreads), 0, s, b, src);
     hipLaunchKernelGGL(k_chain_scan_tiles, dim3(b.A), dim3(kScanThreads), 0, s, b);
     hipLaunchKernelGGL(k_chain_bounds, dim3(tb, b.A), dim3(kThreads), 0, s, b);
-    hipLaunchKernelGGL(k_chain_pass1, dim3((unsigned)((b.cap_chunks * 16 + kThreads - 1) / kThreads), b.A), dim3(kThreads), 0, s, b);
+    const dim3 p1grid((unsigned)((b.cap_chunks * 16 + kThreads - 1) / kThreads), b.A);
+    hipLaunchKernelGGL(k_chain_pass1<false>, p1grid, dim3(kThreads), 0, s, b);
     hipLaunchKernelGGL(k_chain_guess, dim3(b.A), dim3(kScanThreads), 0, s, b);
     const dim3 tgrid((unsigned)((b.cap_chunks + kThreads / 64 - 1) / (kThreads / 64)), b.A);       // one wavefront per chunk
     const size_t lds = chain_stitch_lds(b);
@@ -373,6 +375,8 @@ static void enqueue_chain(rl_trainer *t, const ChainBufs &b, const ChainSource &
             if (!spin_until(b.h_progress, [&](unsigned long long v) { return (v >> 1) >= want; }, w)) hint = false;
             else if ((w >> 17) == seq && !(w & 1)) { clean = true; break; }
         }
+        hipLaunchKernelGGL(k_chain_pass1<true>, p1grid, dim3(kThreads), 0, s, b);
+        hipLaunchKernelGGL(k_chain_recentre, dim3(b.maxseg, b.A), dim3(kScanThreads), 0, s, b);
         hipLaunchKernelGGL(k_chain_tables<true>, tgrid, dim3(kThreads), 0, s, b, 1);
         hipLaunchKernelGGL(k_chain_stitch, dim3(b.maxseg, b.A), dim3(kScanThreads), lds, s, b, 1, (seq << 16) | (unsigned)(rep + 1));
     }
