@@ -365,12 +365,12 @@ static void enqueue_chain(rl_trainer *t, const ChainBufs &b, const ChainSource &
     bool hint = b.h_progress != nullptr && t->step_ahead > 0, clean = false;
     hipLaunchKernelGGL(k_chain_tables<false>, tgrid, dim3(kThreads), 0, s, b, 0);
     hipLaunchKernelGGL(k_chain_stitch, dim3(b.maxseg, b.A), dim3(kScanThreads), lds, s, b, 0, seq << 16);
-    // With the hint the host sees every pass's outcome two passes later, so it can keep repairing for as long as a segment is open
-    // (a chain of tens of millions of elements can meet more than kChainRepairs window misses; each pass costs two short launches, the
-    // serial finish of a chain that long costs 100 ms); without it exactly kChainRepairs passes are enqueued blindly.
+    // With the hint the host sees every stitch's outcome before it enqueues the next repair pass, so it repairs for as long as a segment is open
+    // (a chain of tens of millions of elements needs a pass per window of 8192 chunks and one per window miss; the serial finish of a chain
+    // that long costs 100 ms) and enqueues nothing on a clean round; without it exactly kChainRepairs passes are enqueued blindly.
     for (int rep = 0; rep < (hint ? kChainRepairsMax : kChainRepairs); rep++) {
-        if (hint && rep >= 1) {
-            const unsigned long long want = (seq << 16) | (unsigned)(rep - 1);      // stitch of repair pass rep-2 (0 = the first stitch)
+        if (hint) {      // (a repair pass is four launches: none is enqueued before the stitch it would repair has reported)
+            const unsigned long long want = (seq << 16) | (unsigned)rep;            // the stitch before repair pass rep (0 = the first stitch)
             unsigned long long w;
             if (!spin_until(b.h_progress, [&](unsigned long long v) { return (v >> 1) >= want; }, w)) hint = false;
             else if ((w >> 17) == seq && !(w & 1)) { clean = true; break; }
