@@ -303,6 +303,13 @@ def _chain_cases():
     seg = np.sort(np.concatenate([[0, 0, 1, 2, 513, 1024, n, n], rng.integers(0, n, 40)]))
     yield "ragged segments (empty, 1 element, tile edges)", lam, seg
     yield "single element", np.array([0.1]), None
+    # chains longer than a repair window (8192 chunks of <= 1024 elements, rl_chain.inc): the first stitch takes one window, the passes the rest,
+    # every one with drifts re-measured from the exact state at its first chunk -- what a leaf of ten million documents needs
+    rng2 = np.random.default_rng(78)
+    nl = 12_000_000
+    long_lam = rng2.standard_normal(nl) * np.exp(rng2.standard_normal(nl) * 2)
+    yield "long chain: several repair windows", long_lam, None
+    yield "two long segments and a short one", long_lam, np.array([0, 5_000_001, 5_000_100, nl])
 
 
 @pytest.mark.parametrize("case", list(_chain_cases()), ids=lambda c: c[0].split(" (")[0].replace(" ", "_"))
