@@ -817,6 +817,10 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool de
     hipLaunchKernelGGL(k_tie_eval, dim3(c.F, nx), dim3(kFinThreads), 0, s, c, a);
     hipLaunchKernelGGL(k_tie_finish, dim3(1), dim3(kFinThreads), fin_lds, s, c, a, nodes_in_lds, deferred ? 1 : 0);
     RL_HIP(hipGetLastError());
+    if (nv > 0 && sharded) {      // every rank checked its own documents: a cut that differs anywhere makes every rank grow the tree again
+        int rcd = t->dist->allreduce(d_vflag, 1, DT_I32, OP_MAX, s);
+        if (rcd) return rcd;
+    }
     if (nv > 0) RL_HIP(hipMemcpyAsync(pin, d_vflag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     RL_HIP(hipStreamSynchronize(s));
     mark(4);
@@ -1593,9 +1597,9 @@ int rl_init(rl_trainer *t)
     // sharded runs evaluate the tie-break on gathered arrays through the contiguous-chain path only: with threshold tables too large for its sort
     // (the literal walk reads one rank's documents) they keep the first candidate.  TS is the same on every rank, so is the decision.
     if (t->dist && t->n_ranks > 1 && (size_t)kTsWaves * TS * 4 > (size_t)60 * 1024) c.tie_on = 0;
-    // bit 1: ties over several features that all cut a node the same way are deferred to the end of the tree like plateau ties (one GPU: the check
-    // that it IS one cut reads the node's documents, rl_tie.inc k_tie_verify)
-    if (c.tie_on && !(t->dist && t->n_ranks > 1) && !getenv("RLHIP_TIE_NO_XDEFER")) c.tie_on |= 2;
+    // bit 1: ties over several features that all cut a node the same way are deferred to the end of the tree like plateau ties (the check that it
+    // IS one cut reads the node's documents, rl_tie.inc k_tie_verify: every rank its own, the verdict is all-reduced)
+    if (c.tie_on && !getenv("RLHIP_TIE_NO_XDEFER")) c.tie_on |= 2;
     if (t->p.n_leaves == -1) {      // -leaf -1: the node histograms are sized for floor(N / mls) leaves -- say so before an allocation fails
         const double need = (double)c.NC * F * TS * ((t->p.flags & RL_FLAG_JAVA_ORDER) ? 28.0 : 20.0);
         size_t mem_free = 0, mem_total = 0;

@@ -25,6 +25,8 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     X, lab, qoff = synth.make_dataset(n_docs, n_feat, kind, seed_offset=seed)
+    if "dupcols" in opts:    # the second half of the columns repeats the first: ties over several features that share one cut
+        X = X.copy(); h = n_feat // 2; X[:, h:2 * h] = 2.0 * X[:, :h] + 1.0
     Xs, ls, qs = D.shard(X, lab, qoff, rank, world)
     tr = D.TorchHostTransport()
     estop = 1 if "valid" in opts else 100
