@@ -16,6 +16,7 @@ import ciir.umass.edu.metric.ERRScorer;
 import ciir.umass.edu.metric.MetricScorer;
 import ciir.umass.edu.metric.NDCGScorer;
 import ciir.umass.edu.parsing.ModelLineProducer;
+import ciir.umass.edu.utilities.MergeSorter;
 import ciir.umass.edu.utilities.RankLibError;
 import ciir.umass.edu.utilities.SimpleMath;
 
@@ -92,14 +93,26 @@ public class LambdaMART extends Ranker {
         if (inBlock > 0) RlHipNative.setRows(handle, validation, first, inBlock, X);
     }
 
-    /** a protected field of a RankLib scorer (NDCGScorer.idealGains, APScorer.relDocCount: metric/NDCGScorer.java:32, metric/APScorer.java:33) */
+    /** What a RankLib scorer holds per qid for -qrel (NDCGScorer.idealGains, APScorer.relDocCount: metric/NDCGScorer.java:32, metric/APScorer.java:33).
+     *  Preferred: the public getter INTEGRATION.md adds to the two scorers (getIdealGains() / getRelDocCount(), two lines each) -- no reflection on
+     *  private state, works in a sealed module.  Without the patch the protected field is read reflectively; when neither is reachable training stops
+     *  with a RankLibError that names the flag, never with silently different lambdas. */
     private static Object scorerField(final Object scorer, final Class<?> owner, final String name) {
+        final String getter = "get" + Character.toUpperCase(name.charAt(0)) + name.substring(1);
+        try {
+            return owner.getMethod(getter).invoke(scorer);
+        } catch (final NoSuchMethodException e) {
+            // unpatched RankLib: fall through to the field
+        } catch (final ReflectiveOperationException | RuntimeException e) {
+            throw RankLibError.create("rlhip: " + owner.getSimpleName() + "." + getter + "() failed (needed for -qrel)", e);
+        }
         try {
             final java.lang.reflect.Field f = owner.getDeclaredField(name);
             f.setAccessible(true);
             return f.get(scorer);
         } catch (final ReflectiveOperationException | RuntimeException e) {
-            throw RankLibError.create("rlhip: cannot read " + owner.getSimpleName() + "." + name + " (needed for -qrel); add a getter or open the package", e);
+            throw RankLibError.create("rlhip: cannot read " + owner.getSimpleName() + "." + name + " (needed for -qrel): add the getter " + getter
+                    + "() from INTEGRATION.md to " + owner.getSimpleName() + ", or train without -qrel", e);
         }
     }
 
@@ -176,6 +189,11 @@ public class LambdaMART extends Ranker {
                 bestScoreOnValidationData = fin[1];
                 logger.info(() -> scorer.name() + " on validation data: " + SimpleMath.round(bestScoreOnValidationData, 4));
             }
+            // the block every -ranker 6 log ends with (learning/tree/LambdaMART.java:267-271); impacts[] is all zeros in the reference too
+            // (nothing ever adds to it), so the stable descending sort leaves the features in their own order
+            logger.info(() -> "-- FEATURE IMPACTS");
+            final int[] ftrsSorted = MergeSorter.sort(this.impacts, false);
+            for (final int ftr : ftrsSorted) logger.info(() -> " Feature " + features[ftr] + " reduced error " + impacts[ftr]);
         } finally {
             RlHipNative.destroy(handle);
             handle = 0;

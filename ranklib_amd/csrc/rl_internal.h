@@ -77,7 +77,7 @@ struct SlotRec {
     int32_t tile0, ntiles;                   // partition tiles [tile0, tile0+ntiles) of this step's grid
     int32_t chunk0, nchunks;                 // histogram chunks [chunk0, chunk0+nchunks) (upper bound) of this step's grid
     int32_t nleft;                           // local size of the left child when known in advance (one GPU), else -1
-    long long sq_left;                       // fixed-point sum of lambda^2 over the left child (k_part_scatter)
+    long long sq_left;                       // fixed-point sum of lambda^2 over the BUILT child (k_part_scatter; the sibling's is parent - built)
 };
 
 struct TreeState {
@@ -106,6 +106,7 @@ struct Ctx {
     float lr;
     int32_t rank, n_ranks;
     int32_t Nglobal;              // documents over ALL ranks (== N on one GPU): fixes the lambda^2 exponent, which every rank must share
+    int32_t hist_nt;              // threads per block of the child-node histogram passes (256 / 512 / 1024; launch_hist)
     int32_t node_div, node_min, node_chunk;   // child-node histograms: target chunks per node, smallest / largest chunk (see chunk_docs)
     int32_t n_live; const int32_t *live;   // unsharded runs: features with more than one distinct value (the others can never split); k_hist_finish
                                   // is launched over these only (a third of the Yahoo-shape columns are empty)
@@ -147,8 +148,8 @@ struct Ctx {
     double2 *lw;             // [N] (lambda, weight) of the round, interleaved: the leaf chains gather both with one 16-byte load
     long long *q, *r;
     int32_t *idx[2];
-    long long *ql[2];        // fixed-point lambda in sample-list order (travels with idx through the partitions)
-    long long *rl[2];        // fixed-point lambda^2, likewise
+    long long *ql[2];        // fixed-point lambda in sample-list order, valid for the ranges of BUILT children only (written by the partition
+                             // that creates them; the lists themselves carry document ids alone)
     unsigned long long *tile_desc;   // [nTiles] look-back descriptors of the single-pass partition
     NodeRec *nodes;
     TreeState *st;

@@ -435,6 +435,13 @@ template <bool ROOT>
 static void launch_hist(const Ctx &c, int gx, int gy, size_t lds, hipStream_t s)
 {
     const dim3 g(gx, (gy + 7) & ~7), b(kThreads);      // the XCD-aware block map of k_hist wants a multiple of 8 chunks (the extra blocks exit)
+    if (!ROOT && c.sub == 16 && c.TS <= kHistLdsStride && !c.any_runs && !(c.p8 > 1) && c.hist_nt > kThreads) {
+        // child passes: a step has few chunks (~12 per node), so the chip is mostly idle and every block is a chain of dependent row gathers --
+        // larger blocks keep more of them in flight per chunk
+        if (c.hist_nt >= 1024) hipLaunchKernelGGL((k_hist<false, 16, kHistLdsStride, false, false, 1024>), g, dim3(1024), lds, s, c);
+        else hipLaunchKernelGGL((k_hist<false, 16, kHistLdsStride, false, false, 512>), g, dim3(512), lds, s, c);
+        return;
+    }
     if (c.sub == 16 && c.TS <= kHistLdsStride) {
         // packed rows for the root pass only (measured at c2: 43 % fewer bytes buy the root pass 9 % -- it is bound by LDS atomics, not by HBM --
         // and the child passes nothing: their extra bit-field work costs what the two 128-byte lines per document instead of three save)
@@ -1500,6 +1507,8 @@ int rl_init(rl_trainer *t)
     c.node_div = std::max(4, std::min(12, (int)(12.0 * std::sqrt(136.0 / (double)std::max(F, 1)) + 0.5))); c.node_min = kMinChunk;
     c.fs_size = F; c.seed = t->p.seed;
     if (t->p.feature_sampling_rate > 0.0f && t->p.feature_sampling_rate < 1.0f) c.fs_size = (int32_t)(t->p.feature_sampling_rate * (float)F);   // :274
+    c.hist_nt = kThreads;
+    if (const char *e = getenv("RLHIP_HIST_NT")) c.hist_nt = atoi(e);
     if (const char *e = getenv("RLHIP_NODE_DIV")) c.node_div = std::max(1, atoi(e));          // tuning knobs (tools/), not API
     if (const char *e = getenv("RLHIP_NODE_MIN")) c.node_min = std::max(256, atoi(e) & ~255);
     // largest chunk: smaller ones spread a mid-sized node over more blocks (measured, same box: c1, 1.2 M x 136: 4096 -> +0.9 % / +1.6 % sustained; c2, 3.77 M: -0.7 %;
@@ -1837,7 +1846,6 @@ int rl_init(rl_trainer *t)
     RL_HIP(t->pool.alloc(&c.q, (size_t)N)); RL_HIP(t->pool.alloc(&c.r, (size_t)N));
     RL_HIP(t->pool.alloc(&c.idx[0], (size_t)N)); RL_HIP(t->pool.alloc(&c.idx[1], (size_t)N));
     RL_HIP(t->pool.alloc(&c.ql[0], (size_t)N)); RL_HIP(t->pool.alloc(&c.ql[1], (size_t)N));
-    RL_HIP(t->pool.alloc(&c.rl[0], (size_t)N)); RL_HIP(t->pool.alloc(&c.rl[1], (size_t)N));
     RL_HIP(t->pool.alloc(&c.nodes, (size_t)c.NC + 2)); RL_HIP(t->pool.alloc(&c.st, (size_t)1));
     RL_HIP(hipMemset(c.st, 0, sizeof(TreeState)));
     t->tree_seq = 0;

@@ -25,7 +25,8 @@ def _gather(rl, fids, who):
         raise RankLibError("Error in %s::normalize(): The input ranked list is empty" % who)
     if fids and min(fids) > 0 and all(len(dp.fVals) > max(fids) for dp in rl.rl):
         # every row names every requested feature: one fancy index per list instead of a Python visit per cell
-        return np.nan_to_num(np.stack([np.asarray(dp.fVals, np.float32) for dp in rl.rl])[:, fids], nan=0.0, posinf=np.inf, neginf=-np.inf)
+        # (rows are ragged -- each ends at its own last feature id -- so every row is cut to the requested ids before the stack)
+        return np.nan_to_num(np.stack([np.asarray(dp.fVals, np.float32)[fids] for dp in rl.rl]), nan=0.0, posinf=np.inf, neginf=-np.inf)
     M = np.zeros((rl.size(), len(fids)), np.float32)
     for i, dp in enumerate(rl.rl):
         fv = dp.fVals

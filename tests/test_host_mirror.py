@@ -499,6 +499,18 @@ def test_normalizers_follow_the_java_loops_bit_for_bit(kind):
             assert np.array_equal(pts[i].fVals[1:].view(np.uint32), want[i][1:].view(np.uint32)), (kind, case, i)
 
 
+def test_normalizer_on_ragged_rows_with_a_feature_subset():
+    """rows end at their own last feature id (DataPoint.parse): a subset whose largest id lies below the shortest row must not need equal row lengths"""
+    from ranklib_amd import normalizer as NM
+    from ranklib_amd.learning import DataPoint as DP, RankList as RL
+    a = np.array([np.nan, 1.0, 3.0, 5.0], np.float32)      # features 1..3
+    b = np.array([np.nan, 3.0, 1.0], np.float32)           # features 1..2
+    rl = RL([DP.from_parsed(1.0, "q", "", a.copy()), DP.from_parsed(0.0, "q", "", b.copy())])
+    NM.create("sum").normalize(rl, [1, 2])
+    assert np.array_equal(rl.rl[0].fVals[1:3], np.array([0.25, 0.75], np.float32)) and rl.rl[0].fVals[3] == 5.0
+    assert np.array_equal(rl.rl[1].fVals[1:3], np.array([0.75, 0.25], np.float32))
+
+
 def test_norm_flag_changes_the_training_data_and_unknown_normalizer_is_an_error(tmp_path):
     from ranklib_amd import evaluator as E
     with pytest.raises(Exception) as ei:
