@@ -15,8 +15,10 @@ RCCL).  `--shape c1` runs configs[1] (MSLR-WEB10K-shape, 1.2 M documents).
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...    (the same, launched from outside)
   --scaling weak: N x the shape's documents (the same documents per rank at every N) instead of the same set sharded
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the root histogram, rl::k_hist<true>):
-algorithmic bytes per launch / HIP-event time of that launch measured live on the library's own stream.
+Prints ONE JSON line on rank 0.  `roofline` is for the time-dominant kernel (the child-node histogram passes, rl::k_hist<false>):
+algorithmic bytes per launch / HIP-event time of that launch measured live on the library's own stream, with the counter traffic
+(`traffic`, `frac_traffic`) beside SURVEY.md 8d's figure; `roofline.root_pass` is the root histogram (rl::k_hist<true>) likewise,
+`roofline.lds_atomic_calibration` the measured LDS atomic rates both kernels' atomics are a fraction of.
 `cpu_baseline` is the CPU oracle (java-exact restatement with RankLib's thread split) timed on this box's
 host cores on the same data for a bounded number of rounds.
 """
@@ -234,7 +236,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--shape", default="c2", help="c0 | c1 | c1ns | c2 (ranklib_amd.synth.SHAPES)")
+    ap.add_argument("--shape", default="c2", help="c0 | c1 | c1ns | c2 | c2ns | c3 (ranklib_amd.synth.SHAPES)")
     ap.add_argument("--cpu-rounds", type=int, default=8, help="rounds timed for the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores (RankLib's default -thread)")
     ap.add_argument("--no-timing", action="store_true", help="do not record HIP events around the dominant kernel")
@@ -249,12 +251,14 @@ def main():
     ap.add_argument("--scaling", default="strong", help="strong (default: the SAME data set sharded over --gpus ranks, what BASELINE.json configs[2] states) | "
                                                        "weak (--gpus x the shape's documents: the same documents per rank at every N)")
     ap.add_argument("--c1-trees", type=int, default=1000, help="after the headline run: BASELINE.json configs[1] as stated (c1 shape, this many trees) -> config.c1_full_run (0 = skip; N = 1 only)")
+    ap.add_argument("--ns-rounds", type=int, default=20, help="after the headline run (c2, N = 1): the north-star list-length variant of the same shape, c2ns "
+                    "(~10 docs/query, 377 k queries), timed over this many rounds -> config.c2ns (0 = skip)")
     ap.add_argument("--trees", type=int, default=10000, help="infer: trees in the scored model")
     ap.add_argument("--docs", type=int, default=100000000, help="infer: rows per GPU and step (configs[4]: 100 M = 54.8 GB of rows in HBM)")
     ap.add_argument("--infer-train-rounds", type=int, default=100)
     args = ap.parse_args()
     if args.plain:
-        args.cpu_rounds, args.sustain, args.node_rounds, args.no_pmc, args.no_timing, args.c1_trees = 0, 0, 0, True, True, 0
+        args.cpu_rounds, args.sustain, args.node_rounds, args.no_pmc, args.no_timing, args.c1_trees, args.ns_rounds = 0, 0, 0, True, True, 0, 0
     if args.workload == "infer":
         if not any(a.startswith("--steps") for a in sys.argv):
             args.steps, args.warmup = 3, 1
@@ -415,6 +419,17 @@ def main():
             ms_g, b_g = N.membench(3, 4 << 30, 4, 5, local_rank); gather_gbs = b_g / ms_g / 1e6
         except Exception as ex:       # noqa: BLE001
             sys.stderr.write("membench failed: %r\n" % (ex,))
+    lds_cal = None
+    if not args.plain:
+        try:        # LDS atomic throughput in the histogram kernels' own LDS layout: what "bound by LDS atomics" is a fraction of (rl_debug_membench modes 4..7)
+            lds_cal = {}
+            for name, mode in (("conflict_free", 4), ("random_257_bins", 5), ("same_address", 6), ("random_257_bins_plus_count", 7)):
+                ms_l, n_at = N.membench(mode, 4096, 1, 3, local_rank)
+                lds_cal[name] = n_at / (ms_l * 1e-3) / (256 * 2.4e9)
+            lds_cal["unit"] = "64-bit LDS atomics per CU and clock (256 CUs x 2.4 GHz), three 256-thread blocks per CU, 16 x 264 int64 accumulators per block"
+        except Exception as ex:       # noqa: BLE001
+            sys.stderr.write("LDS atomic calibration failed: %r\n" % (ex,))
+            lds_cal = None
     pmc = None if (args.no_pmc or world != 1) else live_pmc(args.shape)
     lds_atomics = None
     try:      # what the root pass is actually bound by: one ds_add_u64 per (document, feature) outside the feature's most populated bin
@@ -430,42 +445,64 @@ def main():
         alg_bytes = bytes_root / n_root
         achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
         B8d, Bbuilt = b_round(rho_java, nu_java, float(n_docs)), b_round(rho_built, nu_part, float(n_docs))
-        out["roofline"] = {
+        root_traffic = (FETCH_FACTOR_WIDE * pmc["root_FETCH_SIZE"] + pmc["root_WRITE_SIZE"]) if pmc else None
+        root_atoms_clk = (lds_atomics / (per_launch_ms * 1e-3) / (256 * 2.4e9)) if lds_atomics else None
+        nonmode_frac = (lds_atomics / (N_loc * F_)) if lds_atomics else None          # share of the (document, feature) pairs outside the feature's most populated bin
+        root_entry = {
             "kernel": "rl::k_hist<true,16> (root histogram, FeatureHistogram.update)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": (FETCH_FACTOR_WIDE * pmc["root_FETCH_SIZE"] + pmc["root_WRITE_SIZE"]) if pmc else None,
-            "traffic_source": ("live: bench.py re-ran itself under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); bytes = "
-                               "%.1f x FETCH_SIZE + WRITE_SIZE per launch (factors: profiles/r02_fetch_calibration.txt)" % FETCH_FACTOR_WIDE) if pmc else None,
+            "traffic": root_traffic,
+            # the bytes the kernel really moves (counter traffic) over its time: the fraction of peak that describes this build; `frac` above is
+            # SURVEY.md 8d's definition (b = 2 bytes per bin id), more than the packed rows stream
+            "frac_traffic": (root_traffic / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if root_traffic else None,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": per_launch_ms, "launches": int(n_root),
-            # what the kernel's layout actually streams: packed rows (one byte per bin id + a 16-bit mask per 16 features) when no
-            # threshold table has more than 257 entries -- fewer bytes than SURVEY.md 8d's b = 2 figure that `achieved` is defined on
             "layout_bytes_per_launch": N_loc * (((n_feat + 15) // 16) * (18.0 if T_ <= 257 else 32.0) + 8.0),
-            "lds_atomics_per_launch": lds_atomics, "lds_atomics_per_cu_clock": (lds_atomics / (per_launch_ms * 1e-3) / (256 * 2.4e9)) if lds_atomics else None,
-            "note": "algorithmic bytes = N_local*(F*2 B bin ids + 8 B fixed-point lambda); HIP events on the library stream",
-            "measured_copy_GBps": copy_gbs, "measured_read_GBps": read_gbs, "measured_gather32_GBps": gather_gbs,
+            "lds_atomics_per_launch": lds_atomics, "lds_atomics_per_cu_clock": root_atoms_clk,
+            "lds_atomics_frac_of_measured_peak": (root_atoms_clk / lds_cal["random_257_bins"]) if (root_atoms_clk and lds_cal) else None,
+            "note": "algorithmic bytes = N_local*(F*2 B bin ids + 8 B fixed-point lambda) (SURVEY.md 8d, b = 2); layout bytes = what the packed rows hold; HIP events on the library stream",
             "frac_of_measured_read": (achieved / read_gbs) if read_gbs else None,
-            # the whole round against HBM.  rho / nu as the survey defines them (what the JAVA accumulates / partitions:
-            # left children of the committed splits) and as this build moves them (smaller child of every PREPARED node, speculation included)
-            "round": {
-                "rho_java": rho_java, "nu_java": nu_java, "rho_built": rho_built, "nu_partitioned": nu_part,
-                "B_round_8d_bytes": B8d, "B_round_built_bytes": Bbuilt,
-                "round_frac_8d": B8d * rounds_per_s / (HBM_PEAK_GBS * 1e9), "round_frac_built": Bbuilt * rounds_per_s / (HBM_PEAK_GBS * 1e9),
-                "round_frac_built_of_measured_copy": (Bbuilt * rounds_per_s / (copy_gbs * 1e9)) if copy_gbs else None,
-                "note": "B_round = N F b (1+rho) + 8 N (1+rho) + 4 N rho + nu N (b+4+4) + 76 N + (2L-1) F T 12 (SURVEY.md 8d, b = 2); round_frac = B_round x rounds/s / 8e12",
-            },
         }
-        if node:
+        round_entry = {
+            "rho_java": rho_java, "nu_java": nu_java, "rho_built": rho_built, "nu_partitioned": nu_part,
+            "B_round_8d_bytes": B8d, "B_round_built_bytes": Bbuilt,
+            "round_frac_8d": B8d * rounds_per_s / (HBM_PEAK_GBS * 1e9), "round_frac_built": Bbuilt * rounds_per_s / (HBM_PEAK_GBS * 1e9),
+            "round_frac_built_of_measured_copy": (Bbuilt * rounds_per_s / (copy_gbs * 1e9)) if copy_gbs else None,
+            "note": "B_round = N F b (1+rho) + 8 N (1+rho) + 4 N rho + nu N (b+4+4) + 76 N + (2L-1) F T 12 (SURVEY.md 8d, b = 2); round_frac = B_round x rounds/s / 8e12",
+        }
+        if node and node["ms_per_round"] > 0 and node["launches_per_round"] > 0:
+            # the time-dominant kernel: the child-node histogram passes (the largest share of a round), per launch as the contract asks
+            L_round = node["launches_per_round"]
             nb = node["docs_per_round"] * (F_ * 2 + 8 + 4)
-            ach = nb / (node["ms_per_round"] * 1e-3) / 1e9 if node["ms_per_round"] > 0 else 0.0
-            out["roofline"]["node_histograms"] = {
-                "kernel": "rl::k_hist<false,16> (child histograms, FeatureHistogram.construct; the kernel with the largest share of a round)",
-                "ms_per_round": node["ms_per_round"], "launches_per_round": node["launches_per_round"],
-                "docs_accumulated_per_round": node["docs_per_round"], "algorithmic_bytes_per_round": nb,
-                "achieved": ach, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "frac_of_measured_gather32": (ach / gather_gbs) if gather_gbs else None,
-                "traffic_per_round": (FETCH_FACTOR_GATHER32 * pmc["node_FETCH_SIZE"] + pmc.get("node_WRITE_SIZE", 0.0)) if pmc and "node_FETCH_SIZE" in pmc else None,
-                "note": "algorithmic bytes = documents of the accumulated (smaller) children x (F*2 B bin ids + 8 B lambda + 4 B sample id); HIP events around "
-                        "every growth step's launch over %d extra rounds (empty launches of finished trees included); bound by LDS atomic throughput, not HBM (DESIGN.md 4.1)" % args.node_rounds,
+            launch_ms = node["ms_per_round"] / L_round
+            ach = (nb / L_round) / (launch_ms * 1e-3) / 1e9
+            node_traffic_round = (FETCH_FACTOR_GATHER32 * pmc["node_FETCH_SIZE"] + pmc.get("node_WRITE_SIZE", 0.0)) if pmc and "node_FETCH_SIZE" in pmc else None
+            node_atoms = (node["docs_per_round"] * F_ * nonmode_frac * 2.0) if nonmode_frac else None      # a 64-bit sum and a 32-bit count per pair outside the mode bin
+            node_atoms_clk = (node_atoms / (node["ms_per_round"] * 1e-3) / (256 * 2.4e9)) if node_atoms else None
+            out["roofline"] = {
+                "kernel": "rl::k_hist<false,16> (child-node histograms, FeatureHistogram.construct): the kernel with the largest share of a round",
+                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": (node_traffic_round / L_round) if node_traffic_round else None,
+                "frac_traffic": (node_traffic_round / (node["ms_per_round"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if node_traffic_round else None,
+                "traffic_over_algorithmic": (node_traffic_round / nb) if node_traffic_round else None,
+                "algorithmic_bytes_per_launch": nb / L_round, "avg_launch_ms": launch_ms, "launches_per_round": L_round,
+                "ms_per_round": node["ms_per_round"], "docs_accumulated_per_round": node["docs_per_round"], "algorithmic_bytes_per_round": nb,
+                "frac_of_measured_gather32": (ach / gather_gbs) if gather_gbs else None,
+                "lds_atomics_per_cu_clock": node_atoms_clk,
+                "lds_atomics_frac_of_measured_peak": (node_atoms_clk / lds_cal["random_257_bins_plus_count"]) if (node_atoms_clk and lds_cal) else None,
+                "traffic_source": ("live: bench.py re-ran itself under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel trace only); bytes = "
+                                   "%.1f x FETCH_SIZE + WRITE_SIZE (factors: profiles/r02_fetch_calibration.txt)" % FETCH_FACTOR_GATHER32) if pmc else None,
+                "note": "algorithmic bytes (SURVEY.md 8d) = documents of the accumulated (smaller) children x (F*2 B bin ids + 8 B lambda + 4 B sample id); HIP events around "
+                        "every growth step's launch over %d extra rounds (the empty launches of finished trees count as launches); the launches are short and mostly "
+                        "latency-bound (DESIGN.md 4.1, 4.2): most of a step's time is neither bytes nor atomics" % args.node_rounds,
+                "root_pass": root_entry,
             }
+        else:       # (--no-timing / --node-rounds 0: only the root pass was timed)
+            out["roofline"] = dict(root_entry)
+        out["roofline"]["lds_atomic_calibration"] = lds_cal
+        out["roofline"]["measured_copy_GBps"] = copy_gbs
+        out["roofline"]["measured_read_GBps"] = read_gbs
+        out["roofline"]["measured_gather32_GBps"] = gather_gbs
+        out["roofline"]["round"] = round_entry
         out["kernel_ms_per_round"] = {"hist_root": ms_root / args.steps, "lambda": ms_lam / args.steps,
                                       "hist_nodes": node["ms_per_round"] if node else None}
     if world > 1:
@@ -483,14 +520,11 @@ def main():
         out["config"]["sustained_over_rounds"] = args.sustain
     ts = g.array("TIE_STATS")
     out["config"]["tie_break"] = {
-        "mode": "lazy Java-order (exact ties re-decided in the reference's summation order, DESIGN.md 4.13)" if (world == 1 and not args.java_order and not args.first_tie) else
-                ("strict: every candidate from the Java-order histogram" if args.java_order else "first candidate in scan order (sharded run or --first-tie)"),
+        "mode": "lazy Java-order (exact ties re-decided in the reference's summation order, DESIGN.md 4.13; sharded runs gather the chain nodes and do the same)"
+                if (not args.java_order and not args.first_tie) else
+                ("strict: every candidate from the Java-order histogram" if args.java_order else "first candidate in scan order (--first-tie)"),
         "resolutions": int(ts[0]), "nodes": int(ts[1]), "chain_documents": int(ts[3]), "host_ms": float(ts[4]) / 1e3,
         "note": "whole run of this trainer (warm-up, timed, sustained and per-step-timing rounds)"}
-    if "roofline" in out and "node_histograms" in out["roofline"]:
-        # the kernel with the largest share of a round is the child-node histogram, not the root pass `frac` is quoted on
-        out["roofline"]["frac_time_dominant"] = out["roofline"]["node_histograms"]["frac"]
-        out["roofline"]["time_dominant_kernel"] = "rl::k_hist<false,16> (node_histograms)"
     if world == 1 and args.c1_trees > 0 and not args.java_order:
         # BASELINE.json configs[1] as stated: MSLR-WEB10K shape, 1000 trees, 31 leaves, one GPU -- the whole run, not a window of it
         n1, f1, k1, _, l1 = synth.SHAPES["c1"]
@@ -508,6 +542,26 @@ def main():
                                         "rounds_per_s": args.c1_trees / dt1, "seconds": dt1, "ndcg10_train": float(g1.round_metrics(args.c1_trees - 1)[0]),
                                         "tie_resolutions": int(ts1[0]), "tie_host_ms": float(ts1[4]) / 1e3}
         del g1
+
+    if world == 1 and args.ns_rounds > 0 and args.shape == "c2" and not args.java_order:
+        # the north star's own list length ("~10 docs/query") at the same size: SURVEY.md 8d asks for both variants
+        nn, fn, kn, _, ln = synth.SHAPES["c2ns"]
+        Xn, labn, qoffn, qn = synth.make_shard(nn, fn, kn, 0, 1)
+        gn = N.Trainer(n_trees=5 + args.ns_rounds + 100, n_leaves=ln, device=local_rank)
+        gn.set_train(Xn, labn, qoffn)
+        gn.init()
+        gn.boost_rounds_async(5); gn.sync()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        gn.boost_rounds_async(args.ns_rounds); gn.sync()
+        dtn = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        gn.boost_rounds_async(100); gn.sync()
+        dts = time.perf_counter() - t1
+        out["config"]["c2ns"] = {"workload": "c2ns: the same %d docs x %d features with the north star's list length (5..15 docs/query, %d queries), %d leaves, one GPU" % (nn, fn, qn, ln),
+                                 "rounds_per_s": args.ns_rounds / dtn, "steps": args.ns_rounds, "warmup": 5, "sustained_rounds_per_s_next_100": 100 / dts,
+                                 "ndcg10_train": float(gn.round_metrics(5 + args.ns_rounds - 1)[0])}
+        del gn, Xn
 
     if args.cpu_rounds > 0 and world == 1:
         import oracle_ffi as O

@@ -290,8 +290,11 @@ enum {
                                    8 + 8 e: {tree, 0, growth step, slot, documents of the split node, documents of the accumulated child, tie flag, slots of the
                                    step} or {tree, 1, tie kind (1 = thresholds of one feature, 2 = several features), right child?, documents, largest node of
                                    the Java-order derivation chain, nodes in the chain, documents in the chain} for a committed split whose best candidate was tied */
-    RL_ARR_PHASE_CLOCKS = 16    /* int64[64][16] device wall-clock stamps (10 ns) inside the last 64 growth steps; all zero unless the
+    RL_ARR_PHASE_CLOCKS = 16,   /* int64[64][32] device wall-clock stamps (10 ns) inside the last 64 growth steps; all zero unless the
                                    library was built with -DRL_PHASE_CLOCKS (tools/phase_clocks.py) */
+    RL_ARR_BLOCK_TRACE = 22     /* int64[64][3][2048][8] entry / phase / exit stamps (10 ns; [0] entry, [7] exit) of every working block of the partition / child-histogram /
+                                   finish kernels in the growth steps of the tree named by RLHIP_TRACE_TREE (-DRL_PHASE_CLOCKS builds,
+                                   tools/step_trace.py); RL_ERR_STATE when no trace was requested */
 };
 /* The device's two exp implementations (rho of learning/tree/LambdaMART.java:383) on n arguments: the branch-free one the
  * lambda kernels use and the literal fdlibm e_exp transcription; both must equal StrictMath.exp bit for bit. */
@@ -315,7 +318,11 @@ int rl_set_timing_flags(rl_trainer *t, int32_t flags);
  * also the known byte counts that calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE (tools/calib_fetch.sh):
  * mode 0 = copy (16 B per lane; reads + writes `bytes`), 1 = streaming read of `bytes`, 2 = streaming write, 3 = 32-byte row
  * gathers through an ascending index list that takes one row in `stride` (the child-node histogram pattern; 32 B row + 4 B
- * index per entry).  avg_ms = mean HIP-event time of `iters` launches, alg_bytes = algorithmic bytes of one launch. */
+ * index per entry).  avg_ms = mean HIP-event time of `iters` launches, alg_bytes = algorithmic bytes of one launch.
+ * Modes 4..7 = LDS atomic throughput in the histogram kernels' own LDS layout (three 256-thread blocks per CU, 16 rows of 264 int64
+ * accumulators): 4 conflict-free, 5 a random bin of 257 per lane, 6 one bin per wavefront (same address), 7 = 5 plus the 32-bit count atomic
+ * of the child passes; `bytes` = 64-bit atomics per thread, alg_bytes returns the 64-bit atomics of one launch (the calibration
+ * behind bench.py's lds_atomics_frac_of_measured_peak). */
 int rl_debug_membench(int32_t device, int32_t mode, int64_t bytes, int32_t stride, int32_t iters, double *avg_ms, double *alg_bytes);
 int rl_reset_timing(rl_trainer *t);
 

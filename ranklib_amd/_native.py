@@ -38,7 +38,7 @@ class RlTree(C.Structure):
 RL_FLAG_TIMING, RL_FLAG_SERIAL_CHAIN, RL_FLAG_TIMING_NODES, RL_FLAG_JAVA_ORDER, RL_FLAG_FIRST_TIE = 2, 4, 8, 16, 32
 ARR = dict(LAMBDA=1, WEIGHT=2, SCORE=3, VALID_SCORE=4, NBINS=5, THRESHOLDS=6, BINS=7, ROOT_COUNT=8, ROOT_SUM=9,
            QUANT=10, ROOT_SUM_FIXED=11, NDCG_PER_QUERY=12, CHAIN_STATS=13, CHAIN_MISS=14, GROW_STATS=15, PHASE_CLOCKS=16,
-           ROOT_SUM_JAVA=17, GROW_DOCS=18, SPARSE_INFO=19, STEP_LOG=20, TIE_STATS=21)
+           ROOT_SUM_JAVA=17, GROW_DOCS=18, SPARSE_INFO=19, STEP_LOG=20, TIE_STATS=21, BLOCK_TRACE=22)
 KERNEL = dict(HIST_ROOT=0, HIST_NODE=1, LAMBDA=2)
 
 # every symbol include/rlhip.h declares (tests/test_abi.py checks the .so exports all of them)
@@ -211,7 +211,8 @@ def set_err_max(max_gain):
 
 
 def membench(mode, nbytes, stride=1, iters=10, device=0):
-    """rl_debug_membench: (avg ms per launch, algorithmic bytes per launch); mode: 0 copy, 1 read, 2 write, 3 32-byte row gather"""
+    """rl_debug_membench: (avg ms per launch, algorithmic bytes per launch); mode: 0 copy, 1 read, 2 write, 3 32-byte row gather;
+    4..7 LDS atomics (conflict-free / random 257 bins / same address / random + count): nbytes = atomics per thread, returns (ms, atomics per launch)"""
     ms, b = C.c_double(0), C.c_double(0)
     check(lib().rl_debug_membench(device, mode, nbytes, stride, iters, C.byref(ms), C.byref(b)))
     return ms.value, b.value
@@ -419,7 +420,7 @@ class Trainer:
             "THRESHOLDS": ((self.F, TS), np.float32), "BINS": ((self.F, self.N), np.uint16),
             "ROOT_COUNT": ((self.F, TS), np.int32), "ROOT_SUM": ((self.F, TS), np.float64), "ROOT_SUM_JAVA": ((self.F, TS), np.float64),
             "QUANT": ((self.N,), np.int64), "ROOT_SUM_FIXED": ((self.F, TS, 2), np.int64),
-            "NDCG_PER_QUERY": ((self.Q,), np.float64), "CHAIN_STATS": ((6,), np.int32), "GROW_STATS": ((4,), np.int32), "GROW_DOCS": ((4,), np.int64), "SPARSE_INFO": ((4,), np.int64), "PHASE_CLOCKS": ((64, 16), np.int64), "STEP_LOG": ((8 + 8 * 8192,), np.int32), "TIE_STATS": ((10,), np.int64), "CHAIN_MISS": ((2, self.cap + 1), np.int32),
+            "NDCG_PER_QUERY": ((self.Q,), np.float64), "CHAIN_STATS": ((6,), np.int32), "GROW_STATS": ((4,), np.int32), "GROW_DOCS": ((4,), np.int64), "SPARSE_INFO": ((4,), np.int64), "PHASE_CLOCKS": ((64, 32), np.int64), "BLOCK_TRACE": ((64, 3, 2048, 8), np.int64), "STEP_LOG": ((8 + 8 * 8192,), np.int32), "TIE_STATS": ((10,), np.int64), "CHAIN_MISS": ((2, self.cap + 1), np.int32),
         }
         shape, dt = shapes[name]
         out = np.zeros(shape, dt)

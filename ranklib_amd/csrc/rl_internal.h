@@ -106,6 +106,7 @@ struct Ctx {
     float lr;
     int32_t rank, n_ranks;
     int32_t Nglobal;              // documents over ALL ranks (== N on one GPU): fixes the lambda^2 exponent, which every rank must share
+    int32_t sub_child;            // features per block of the child-node histogram passes (16, or 8 / 4: RLHIP_SUB_CHILD)
     int32_t hist_nt;              // threads per block of the child-node histogram passes (256 / 512 / 1024; launch_hist)
     int32_t node_div, node_min, node_chunk;   // child-node histograms: target chunks per node, smallest / largest chunk (see chunk_docs)
     int32_t n_live; const int32_t *live;   // unsharded runs: features with more than one distinct value (the others can never split); k_hist_finish
@@ -187,7 +188,9 @@ struct Ctx {
     double *jcum;            // [NC][F][TS] cumulative Java-order sums of every live node
     const uint16_t *jmap, *jinv; const uint32_t *jone;      // k_jhist2: bin -> owning (wavefront, lane), its inverse, single-bin wavefronts (null: k_jhist)
     int32_t *steplog;        // debug (RLHIP_STEPLOG=1, RL_ARR_STEP_LOG): [0] = entries written, then 8-int entries: growth-step slots and committed tied splits
-    long long *clk;          // [64][16] wall-clock stamps (10 ns units) of the finish / select phases of the last 64 growth steps; only
+    int32_t trace_tree;      // -DRL_PHASE_CLOCKS builds: the tree (TreeState::tree_seq while it grows) whose growth kernels record their spans (RLHIP_TRACE_TREE)
+    long long *trace;        // [64][3][kTraceBlocks][2] entry / exit stamps of the growth kernels' blocks (null unless RLHIP_TRACE_TREE is set)
+    long long *clk;          // [64][32] wall-clock stamps (10 ns units) of the finish / select phases of the last 64 growth steps; only
                              // written by builds with -DRL_PHASE_CLOCKS (tools/phase_clocks.py), RL_ARR_PHASE_CLOCKS reads it
 };
 

@@ -434,7 +434,20 @@ static int launch_rank(rl_trainer *t, DataSet &d, const double *scores, double *
 template <bool ROOT>
 static void launch_hist(const Ctx &c, int gx, int gy, size_t lds, hipStream_t s)
 {
-    const dim3 g(gx, (gy + 7) & ~7), b(kThreads);      // the XCD-aware block map of k_hist wants a multiple of 8 chunks (the extra blocks exit)
+    // the XCD-aware block map of k_hist wants a multiple of 8 chunks (the extra blocks exit); child passes: a bounded grid whose blocks walk the
+    // step's chunks (k_hist), about one resident set of blocks (3 per CU)
+    static const int grid_blocks = getenv("RLHIP_HIST_GRID") ? atoi(getenv("RLHIP_HIST_GRID")) : 1024;
+    const auto bounded = [&](int gxx) { return ROOT ? ((gy + 7) & ~7) : std::min((gy + 7) & ~7, std::max(8, ((grid_blocks + gxx - 1) / gxx + 7) & ~7)); };
+    const dim3 g(gx, bounded(gx)), b(kThreads);
+    if (!ROOT && c.sub == 16 && c.TS <= kHistLdsStride && !c.any_runs && !(c.p8 > 1) && c.sub_child < 16) {
+        // child passes, features of a group spread over 16 / sub_child blocks: a step of a few chunks leaves most CUs idle while every block is bound by
+        // the LDS atomics of ITS CU -- the same atomics on more CUs (the rows are read once per sub-block, from L2)
+        const dim3 g2(gx * (16 / c.sub_child), bounded(gx * (16 / c.sub_child)));
+        const size_t lds2 = (size_t)c.sub_child * kHistLdsStride * 12;
+        if (c.sub_child == 8) hipLaunchKernelGGL((k_hist<false, 8, kHistLdsStride, false, false, 256>), g2, dim3(256), lds2, s, c);
+        else hipLaunchKernelGGL((k_hist<false, 4, kHistLdsStride, false, false, 256>), g2, dim3(256), lds2, s, c);
+        return;
+    }
     if (!ROOT && c.sub == 16 && c.TS <= kHistLdsStride && !c.any_runs && !(c.p8 > 1) && c.hist_nt > kThreads) {
         // child passes: a step has few chunks (~12 per node), so the chip is mostly idle and every block is a chain of dependent row gathers --
         // larger blocks keep more of them in flight per chunk
@@ -1507,7 +1520,8 @@ int rl_init(rl_trainer *t)
     c.node_div = std::max(4, std::min(12, (int)(12.0 * std::sqrt(136.0 / (double)std::max(F, 1)) + 0.5))); c.node_min = kMinChunk;
     c.fs_size = F; c.seed = t->p.seed;
     if (t->p.feature_sampling_rate > 0.0f && t->p.feature_sampling_rate < 1.0f) c.fs_size = (int32_t)(t->p.feature_sampling_rate * (float)F);   // :274
-    c.hist_nt = kThreads;
+    c.hist_nt = kThreads; c.sub_child = 16;
+    if (const char *e = getenv("RLHIP_SUB_CHILD")) { const int v = atoi(e); if (v == 4 || v == 8) c.sub_child = v; }
     if (const char *e = getenv("RLHIP_HIST_NT")) c.hist_nt = atoi(e);
     if (const char *e = getenv("RLHIP_NODE_DIV")) c.node_div = std::max(1, atoi(e));          // tuning knobs (tools/), not API
     if (const char *e = getenv("RLHIP_NODE_MIN")) c.node_min = std::max(256, atoi(e) & ~255);
@@ -1893,7 +1907,14 @@ int rl_init(rl_trainer *t)
     RL_HIP(t->pool.alloc(&c.grow_docs, (size_t)4)); RL_HIP(hipMemset(c.grow_docs, 0, 32));
     c.steplog = nullptr;
     if (getenv("RLHIP_STEPLOG")) { RL_HIP(t->pool.alloc(&c.steplog, (size_t)8 + 8 * kStepLogCap)); RL_HIP(hipMemset(c.steplog, 0, ((size_t)8 + 8 * kStepLogCap) * sizeof(int32_t))); }
-    RL_HIP(t->pool.alloc(&c.clk, (size_t)64 * 16)); RL_HIP(hipMemset(c.clk, 0, 64 * 16 * sizeof(long long)));
+    RL_HIP(t->pool.alloc(&c.clk, (size_t)64 * 32));
+    RL_HIP(hipMemset(c.clk, 0, 64 * 32 * sizeof(long long)));
+    c.trace_tree = -1;
+    c.trace = nullptr;
+    if (const char *e = getenv("RLHIP_TRACE_TREE")) {
+        c.trace_tree = atoi(e);
+        RL_HIP(t->pool.alloc(&c.trace, (size_t)64 * 3 * kTraceBlocks * kTraceStamps)); RL_HIP(hipMemset(c.trace, 0, (size_t)64 * 3 * kTraceBlocks * kTraceStamps * sizeof(long long)));
+    }
     RL_HIP(t->pool.alloc(&c.leaf_node, (size_t)c.MAXN + 1)); RL_HIP(t->pool.alloc(&c.leaf_start, (size_t)c.MAXN + 2));
     RL_HIP(t->pool.alloc(&c.round_metric, (size_t)2 * t->p.n_trees));
     RL_HIP(hipMemset(c.round_metric, 0, (size_t)2 * t->p.n_trees * sizeof(float)));
@@ -2289,7 +2310,8 @@ int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes)
         else memset(out, 0, bytes);
         return RL_OK;
     }
-    case RL_ARR_PHASE_CLOCKS: src = c.clk; bytes = 64 * 16 * sizeof(long long); break;
+    case RL_ARR_PHASE_CLOCKS: src = c.clk; bytes = 64 * 32 * sizeof(long long); break;
+    case RL_ARR_BLOCK_TRACE: if (!c.trace) return fail(RL_ERR_STATE, "no block trace (RLHIP_TRACE_TREE unset)"); src = c.trace; bytes = (size_t)64 * 3 * kTraceBlocks * kTraceStamps * sizeof(long long); break;
     case RL_ARR_CHAIN_STATS: {
         if (cap_bytes < 24) return fail(RL_ERR_INVALID, "output buffer too small");
         RL_HIP(hipMemcpy(out, (t->dist ? t->gchain : t->leaf_chain).stats, 12, hipMemcpyDeviceToHost));
@@ -2395,8 +2417,34 @@ int rl_debug_float_chain(int32_t device, const double *x, int64_t n, const int64
 
 int rl_debug_membench(int32_t device, int32_t mode, int64_t bytes, int32_t stride, int32_t iters, double *avg_ms, double *alg_bytes)
 {
-    if (!avg_ms || bytes < 4096 || iters < 1 || mode < 0 || mode > 3 || (mode == 3 && stride < 1)) return fail(RL_ERR_INVALID, "bad argument");
+    if (!avg_ms || bytes < 4096 || iters < 1 || mode < 0 || mode > 7 || (mode == 3 && stride < 1)) return fail(RL_ERR_INVALID, "bad argument");
     RL_HIP(hipSetDevice(device));
+    if (mode >= 4) {
+        // LDS atomics (k_mb_lds_atomic): `bytes` = atomics per thread (rounded to 16), `stride` unused; alg_bytes returns the 64-bit atomics of one launch
+        hipDeviceProp_t prop;
+        RL_HIP(hipGetDeviceProperties(&prop, device));
+        const int reps = (int)std::max<int64_t>(1, bytes / 16);
+        const unsigned gridl = (unsigned)prop.multiProcessorCount * 3u;
+        unsigned long long *sinkl = nullptr;
+        RL_HIP(hipMalloc((void **)&sinkl, gridl * sizeof(unsigned long long)));
+        struct G2 { unsigned long long *p; ~G2() { (void)hipFree(p); } } g2{sinkl};
+        hipEvent_t e0, e1;
+        RL_HIP(hipEventCreate(&e0)); RL_HIP(hipEventCreate(&e1));
+        const size_t ldsb = (size_t)16 * kHistLdsStride * 12;
+        for (int it = -1; it < iters; it++) {
+            if (it == 0) RL_HIP(hipEventRecord(e0, nullptr));
+            hipLaunchKernelGGL(k_mb_lds_atomic, dim3(gridl), dim3(kThreads), ldsb, nullptr, mode - 4, reps, sinkl);
+        }
+        RL_HIP(hipEventRecord(e1, nullptr));
+        RL_HIP(hipEventSynchronize(e1));
+        RL_HIP(hipGetLastError());
+        float ms = 0;
+        RL_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        *avg_ms = (double)ms / iters;
+        if (alg_bytes) *alg_bytes = (double)gridl * kThreads * (double)reps * 16.0;
+        return RL_OK;
+    }
     const size_t n16 = (size_t)bytes / 16;
     uint4 *a = nullptr, *b = nullptr; int *idx = nullptr; unsigned *sink = nullptr;
     struct Guard { void **p[4]; ~Guard() { for (auto q : p) if (*q) (void)hipFree(*q); } } guard{{(void **)&a, (void **)&b, (void **)&idx, (void **)&sink}};

@@ -134,6 +134,7 @@ SHAPES = {
     "c1": (1_200_000, 136, "mslr", 1000, 31),
     "c1ns": (1_200_000, 136, "ns", 1000, 31),
     "c2": (3_770_000, 136, "mslr", 1000, 31),
+    "c2ns": (3_770_000, 136, "ns", 1000, 31),     # the north star's "~10 docs/query" at the WEB30K size (SURVEY.md 8d asks for both list-length variants)
     "c3": (473_000, 700, "yahoo", 1000, 31),      # Yahoo-set1 shape: sparse, 700 features (181 empty)
 }
 
