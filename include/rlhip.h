@@ -279,8 +279,9 @@ enum {
     RL_ARR_GROW_DOCS = 18,      /* int64[4] cumulative documents: accumulated into child histograms (the smaller child of every prepared
                                    node), partitioned, left children of committed splits (= what the Java accumulates: the rho of
                                    SURVEY.md 8d times N), committed split nodes (nu times N) */
-    RL_ARR_SPARSE_INFO = 19,    /* int64[4]: 16-feature groups whose root histogram comes from sparse-column entry lists (rl_csc.inc), entries,
-                                   groups read as dense rows, live columns in the sparse groups */
+    RL_ARR_SPARSE_INFO = 19,    /* int64[8]: 16-feature groups whose root histogram comes from sparse-column entry lists (rl_csc.inc), entries,
+                                   groups read as dense rows, live columns in the sparse groups; groups whose child passes read compact rows (0 = off),
+                                   their entries (cells outside the mode bins), rows with more than eight entries (dense fallback), row stride */
     RL_ARR_TIE_STATS = 21,      /* int64[10] cumulative, the lazy Java-order tie-break: resolutions run by the host (stalled trees + batches), nodes
                                    whose tied best split was re-decided in the Java's summation order, nodes and documents of the derivation chains that were summed,
                                    host microseconds spent resolving, chain segments evaluated speculatively, candidate-window misses, segments run serially,

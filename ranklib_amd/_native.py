@@ -420,7 +420,7 @@ class Trainer:
             "THRESHOLDS": ((self.F, TS), np.float32), "BINS": ((self.F, self.N), np.uint16),
             "ROOT_COUNT": ((self.F, TS), np.int32), "ROOT_SUM": ((self.F, TS), np.float64), "ROOT_SUM_JAVA": ((self.F, TS), np.float64),
             "QUANT": ((self.N,), np.int64), "ROOT_SUM_FIXED": ((self.F, TS, 2), np.int64),
-            "NDCG_PER_QUERY": ((self.Q,), np.float64), "CHAIN_STATS": ((6,), np.int32), "GROW_STATS": ((4,), np.int32), "GROW_DOCS": ((4,), np.int64), "SPARSE_INFO": ((4,), np.int64), "PHASE_CLOCKS": ((64, 32), np.int64), "BLOCK_TRACE": ((64, 3, 2048, 8), np.int64), "STEP_LOG": ((8 + 8 * 8192,), np.int32), "TIE_STATS": ((10,), np.int64), "CHAIN_MISS": ((2, self.cap + 1), np.int32),
+            "NDCG_PER_QUERY": ((self.Q,), np.float64), "CHAIN_STATS": ((6,), np.int32), "GROW_STATS": ((4,), np.int32), "GROW_DOCS": ((4,), np.int64), "SPARSE_INFO": ((8,), np.int64), "PHASE_CLOCKS": ((64, 32), np.int64), "BLOCK_TRACE": ((64, 3, 2048, 8), np.int64), "STEP_LOG": ((8 + 8 * 8192,), np.int32), "TIE_STATS": ((10,), np.int64), "CHAIN_MISS": ((2, self.cap + 1), np.int32),
         }
         shape, dt = shapes[name]
         out = np.zeros(shape, dt)

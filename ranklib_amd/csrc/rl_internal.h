@@ -131,6 +131,8 @@ struct Ctx {
     const unsigned char *pbins;     // [numFG][Npad][16]  group-major low bytes (root pass)
     const uint16_t *phib;           // [numFG][Npad]      group-major masks
     const unsigned char *pdbins;    // [Npad][pd_stride]  document-major rows (child passes)
+    const uint8_t *cr_grp;        // [numFG] 1 = the group's child passes read compact rows (block-uniform choice; the others keep the 32-byte rows)
+    const uint4 *crows; int32_t cr_stride;   // compact rows [Npad][cr_stride] of sparse data (k_compact_rows; null = off): the child passes read these instead of dbins
     int32_t dm_gstride;        // groups per document row of dbins: numFG rounded up to a multiple of 4 (rows start on 128-byte lines)
     int32_t dm_root, dm_div;   // document-major rows for the root pass (0 / 1); for a node of cnt samples when cnt * dm_div <= N (0 = never, 1 = every child)
     int32_t sub;            // features of a group handled per histogram block (kHistFG unless the threshold table is huge)

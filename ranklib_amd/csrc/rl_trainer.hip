@@ -89,6 +89,7 @@ struct rl_trainer {
     EnsTree ens;
     int32_t L_eff = 0;          // leaf budget in force: n_leaves, or floor(N / min_leaf_support) for -leaf -1
     int64_t sp_entries = 0; int32_t sp_cols = 0;      // sparse-column path of the root pass (rl_csc.inc)
+    int32_t cr_groups = 0; double cr_entries = 0, cr_overflow = 0;          // compact rows (groups that use them; of the child passes (k_compact_rows): entries outside the mode bins, rows that need the dense fallback
     double err_max = 16.0;      // ERRScorer.MAX when the trainer was created (rl_set_err_max)
     int32_t round = 0;          // rounds enqueued so far
     // growth progress reported by the device (Ctx::progress): the host keeps at most `step_ahead` growth steps in flight and
@@ -439,6 +440,10 @@ static void launch_hist(const Ctx &c, int gx, int gy, size_t lds, hipStream_t s)
     static const int grid_blocks = getenv("RLHIP_HIST_GRID") ? atoi(getenv("RLHIP_HIST_GRID")) : 1024;
     const auto bounded = [&](int gxx) { return ROOT ? ((gy + 7) & ~7) : std::min((gy + 7) & ~7, std::max(8, ((grid_blocks + gxx - 1) / gxx + 7) & ~7)); };
     const dim3 g(gx, bounded(gx)), b(kThreads);
+    if (!ROOT && c.crows && c.sub == 16 && c.TS <= kHistLdsStride && !c.any_runs) {      // sparse data: compact rows (k_compact_rows)
+        hipLaunchKernelGGL((k_hist<false, 16, kHistLdsStride, false, false, kThreads, true>), g, b, lds, s, c);
+        return;
+    }
     if (!ROOT && c.sub == 16 && c.TS <= kHistLdsStride && !c.any_runs && !(c.p8 > 1) && c.sub_child < 16) {
         // child passes, features of a group spread over 16 / sub_child blocks: a step of a few chunks leaves most CUs idle while every block is bound by
         // the LDS atomics of ITS CU -- the same atomics on more CUs (the rows are read once per sub-block, from L2)
@@ -1708,6 +1713,40 @@ int rl_init(rl_trainer *t)
         RL_HIP(hipMemcpy(d_runs, h_runs.data(), h_runs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         c.runs = d_runs;
     }
+    c.crows = nullptr; c.cr_stride = 0; c.cr_grp = nullptr;
+    {   // compact rows for the child passes of sparse data (BASELINE.json configs[3]: 85 % of the cells sit in their column's mode bin), decided per
+        // 16-column group: a group takes them when its rows average at most 5 entries outside the mode bins and at most one row in 20 needs the
+        // dense fallback; built when at least half of the groups do.  RLHIP_CROWS=0 / 1 forces them off / on for every group
+        const char *e = getenv("RLHIP_CROWS");
+        const int force = e ? atoi(e) : -1;
+        if (force != 0 && TS <= kHistLdsStride && c.sub == 16) {
+            unsigned long long *d_st = nullptr; uint4 *d_cr = nullptr;
+            const int crs = (c.numFG + 7) & ~7;           // rows start on 128-byte lines
+            RL_HIP(t->pool.alloc(&d_st, (size_t)2 * c.numFG)); RL_HIP(hipMemsetAsync(d_st, 0, (size_t)2 * c.numFG * sizeof(unsigned long long), s));
+            RL_HIP(t->pool.alloc(&d_cr, (size_t)Npad * crs));
+            RL_HIP(hipMemsetAsync(d_cr, 0xff, (size_t)Npad * crs * sizeof(uint4), s));
+            hipLaunchKernelGGL(k_compact_rows, dim3(4096), dim3(kThreads), 0, s, (const uint16_t *)d_gbins, (const int32_t *)d_mode, d_cr, N, Npad, c.numFG, crs, F, d_st);
+            std::vector<unsigned long long> h_st((size_t)2 * c.numFG);
+            RL_HIP(hipMemcpyAsync(h_st.data(), d_st, h_st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            RL_HIP(hipStreamSynchronize(s));
+            t->pool.release(d_st);
+            std::vector<uint8_t> h_cg((size_t)c.numFG, 0);
+            int n_on = 0; double ents = 0, over = 0;
+            for (int g = 0; g < c.numFG; g++) {
+                const double eg = (double)h_st[2 * g], og = (double)h_st[2 * g + 1];
+                const bool on = force == 1 || (eg <= 5.0 * (double)N && og * 20.0 <= (double)N);
+                h_cg[g] = on ? 1 : 0;
+                if (on) { n_on++; ents += eg; over += og; }
+            }
+            if (force == 1 || 2 * n_on >= c.numFG) {
+                uint8_t *d_cg = nullptr;
+                RL_HIP(t->pool.alloc(&d_cg, (size_t)c.numFG));
+                RL_HIP(hipMemcpy(d_cg, h_cg.data(), h_cg.size(), hipMemcpyHostToDevice));
+                c.crows = d_cr; c.cr_stride = crs; c.cr_grp = d_cg;
+                t->cr_groups = n_on; t->cr_entries = ents; t->cr_overflow = over;
+            } else t->pool.release(d_cr);
+        }
+    }
     RL_HIP(hipGetLastError());
     RL_HIP(hipStreamSynchronize(s));
     t->pool.release(Xt); t->pool.release(thr0); t->pool.release(fs.set);
@@ -2291,7 +2330,8 @@ int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes)
     case RL_ARR_GROW_STATS: src = c.grow_stats; bytes = 16; break;
     case RL_ARR_GROW_DOCS: src = c.grow_docs; bytes = 32; break;
     case RL_ARR_SPARSE_INFO: {
-        const int64_t v[4] = {c.sp_on ? c.sp_ngroups : 0, t->sp_entries, c.sp_on ? c.numFG - c.sp_ngroups : c.numFG, t->sp_cols};
+        const int64_t v[8] = {c.sp_on ? c.sp_ngroups : 0, t->sp_entries, c.sp_on ? c.numFG - c.sp_ngroups : c.numFG, t->sp_cols,
+                              c.crows ? t->cr_groups : 0, (int64_t)t->cr_entries, (int64_t)t->cr_overflow, c.cr_stride};
         if (cap_bytes < (int64_t)sizeof(v)) return fail(RL_ERR_INVALID, "output buffer too small");
         memcpy(out, v, sizeof(v));
         return RL_OK;

@@ -97,9 +97,10 @@ def test_fullsize_determinism_c1():
             assert np.array_equal(x["tree"][k], y["tree"][k])
 
 
-@pytest.mark.parametrize("shape,rounds,strict", [("c1", 3, False), ("c2", 3, False), ("c1", 2, True), ("c2", 2, True)])
+@pytest.mark.parametrize("shape,rounds,strict", [("c1", 3, False), ("c2", 3, False), ("c1", 2, True), ("c2", 2, True), ("c3", 2, False)])
 def test_fullsize_oracle_parity(shape, rounds, strict):
-    """c1 / c2 against the CPU oracle run with RankLib's MyThreadPool work split on every host thread
+    """c1 / c2 / c3 (BASELINE.json configs[1..3] at full size; c3 = 473 k x 700 sparse columns: entry lists in the root pass, compact rows in the
+    child passes) against the CPU oracle run with RankLib's MyThreadPool work split on every host thread
     (learning/tree/LambdaMART.java:169-272): thresholds, bins, root counts at init; lambda, weight, scores, per-round metric
     bit for bit; trees through tree_equiv, and NO split may store another (feature, threshold) than the oracle's -- with the default flags
     (exact ties are re-decided in the Java's summation order, rl_tie.inc) and in the strict mode (RL_FLAG_JAVA_ORDER)."""
@@ -120,6 +121,9 @@ def test_fullsize_oracle_parity(shape, rounds, strict):
         assert np.array_equal(bins[f].astype(np.int32), o.bins(f)), f
         assert np.array_equal(cnt[f, :T], o.root_count(f)), f
     del bins
+    if shape == "c3":
+        info = g.array("SPARSE_INFO")
+        assert info[0] > 0 and info[4] >= 30, "the sparse paths (root: entry lists, children: compact rows) must be the ones that run at c3: %s" % info.tolist()
     stats = {}
     t_or = 0.0
     for r in range(rounds):

@@ -672,7 +672,7 @@ def test_bad_inputs_are_rejected_with_ranklib_style_errors():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["sparse", "dense"])
+@pytest.mark.parametrize("mode", ["sparse", "dense", "rows"])
 def test_sparse_700_feature_shape_matches_the_oracle(mode, monkeypatch):
     """Yahoo-set1 shape (BASELINE.json configs[3]) in small: 700 columns, 175 of them all zero (one threshold + MAX_VALUE,
     never split on), the rest 85 % zeros.  The tree learner densifies everything (learning/SparseDataPoint.java:82-95), so only the
@@ -680,12 +680,17 @@ def test_sparse_700_feature_shape_matches_the_oracle(mode, monkeypatch):
     with RLHIP_CSC_DENS=0, the dense rows.  Both must give the oracle's trees / scores / metrics: the paths are bit-identical."""
     if mode == "dense":
         monkeypatch.setenv("RLHIP_CSC_DENS", "0")
+    if mode != "sparse":
+        monkeypatch.setenv("RLHIP_CROWS", "0")          # child passes from the 32-byte rows instead of the compact rows
     X, lab, qoff = make(6000, 700, "yahoo", 31)
     o, g = pair(X, lab, qoff, n_trees=4, n_leaves=12)
     o.init(); g.init()
     nb = g.array("NBINS")
     assert (nb[np.abs(X).sum(0) == 0] == 2).all()
     info = g.array("SPARSE_INFO")
+    assert (info[4] >= 30) if mode == "sparse" else (info[4] == 0), info          # compact rows of the child passes: on by themselves for the groups of 85 %-zero columns
+    if mode == "sparse":
+        assert 0 < info[5] <= int((X != 0).sum()) and info[6] * 20 <= 6000 * info[4], info    # entries = cells outside the mode bins of those groups; few dense fallbacks
     if mode == "dense":
         assert info[0] == 0 and info[1] == 0 and info[2] == 44
     else:
@@ -704,6 +709,30 @@ def test_sparse_700_feature_shape_matches_the_oracle(mode, monkeypatch):
         for f in np.nonzero(nb > 2)[0][:60]:
             hi, lo = int(fixed[f, nb[f] - 1, 0]), int(fixed[f, nb[f] - 1, 1]) & 0xFFFFFFFFFFFFFFFF
             assert hi * 2 ** 64 + lo == tot, (r, f)
+
+
+@pytest.mark.parametrize("kind,nfeat", [("mslr", 40), ("mixed", 48)])
+def test_compact_rows_forced_on_dense_and_mixed_data(kind, nfeat, monkeypatch):
+    """RLHIP_CROWS=1 on data the heuristic would never pick: dense MSLR-shaped columns (every row has more than eight entries outside the mode bins
+    and is read through the dense fallback of the compact-row kernel) and a mix of sparse and dense groups (both kinds of row in one launch).
+    The partial histograms are the same atomics either way: trees, scores and metrics equal the oracle's."""
+    monkeypatch.setenv("RLHIP_CROWS", "1")
+    rng = np.random.default_rng(11)
+    X, lab, qoff = make(7000, nfeat, "mslr", 43)
+    if kind == "mixed":
+        X = X.copy()
+        for f in range(16, 40):
+            X[rng.random(7000) < (0.93 if f < 32 else 0.6), f] = 0.0      # group 1: <= a couple of entries a row; group 2: around the limit of eight
+    o, g = pair(X, lab, qoff, n_trees=3, n_leaves=14)
+    o.init(); g.init()
+    info = g.array("SPARSE_INFO")
+    assert info[4] == (nfeat + 15) // 16 and info[6] > 0, info          # on for every group, and some rows take the dense fallback
+    for r in range(3):
+        to, tmo, _, _ = o.round()
+        tg, tmg, _, _ = g.boost_round()
+        assert_same_tree(to, tg, X, "round %d" % r)
+        assert np.array_equal(g.array("SCORE").view(np.int64), o.scores().view(np.int64))
+        assert tmo == tmg
 
 
 def test_mixed_sparse_and_dense_columns():
