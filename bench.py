@@ -125,6 +125,21 @@ def bench_infer(args):
     nt = m.num_trees()
     # mean path length on the training distribution from the per-node training counts
     visits = float(np.mean([t["count"][t["feature"] != -1].sum() / t["count"][0] for t in trees]))
+
+    def depth_of(t):        # levels below the root of the deepest leaf
+        d = np.zeros(len(t["feature"]), np.int32)
+        for i in range(len(t["feature"])):      # (trimmed trees list a parent before its children)
+            if t["feature"][i] != -1:
+                d[int(t["left"][i])] = d[int(t["right"][i])] = d[i] + 1
+        return int(d.max())
+    # lockstep walk length per tree as the kernel deals the trees of a 32-tree tile to its four walker wavefronts (by descending depth, eight each)
+    dep = np.array([max(depth_of(trees[i % len(trees)]), 1) for i in range(args.trees)])
+    steps_sum = 0
+    for a in range(0, len(dep), 32):
+        ds_ = np.sort(dep[a:a + 32])[::-1]
+        for q in range(0, len(ds_), 8):
+            steps_sum += int(ds_[q]) * len(ds_[q:q + 8])
+    walk_steps = steps_sum / float(len(dep))
     n = args.docs
     stride = F + 1
     gen = torch.Generator(device="cuda").manual_seed(20240601 + rank)
@@ -173,10 +188,20 @@ def bench_infer(args):
                                "%d trees (%d trained rounds tiled), 31 leaves" % (n, F, world, nt, args.infer_train_rounds),
                    "mean_node_visits_per_tree": visits, "node_visits_per_s": docs_per_s * nt * visits,
                    "model_parse_seconds": round(t_load, 2)},
-        "roofline": {"kernel": "rl::k_model_eval_tiled", "bound": "hbm", "achieved": n * stride * 4.0 / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": n * stride * 4.0 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "note": "HBM is not the limiter here: every row is read once and visited %d x %.1f times in LDS; the kernel is bound by "
-                             "LDS / VALU issue (DESIGN.md 4.8), node_visits_per_s is the figure of merit" % (nt, visits)},
+        "roofline": {
+            # the walk is bound by instruction issue, not by bytes: a chain step is 5 vector-ALU + 2 LDS wave-instructions for 64 lanes.
+            # peak = what the four SIMDs of a CU issue if they did nothing else: 4 SIMDs x 64 lanes / (5 VALU x 4 cycles) lane-steps per CU and clock.
+            "kernel": "rl::k_model_eval_tiled", "bound": "valu_issue",
+            "achieved": docs_per_s / world * nt * walk_steps / (256 * 2.4e9), "peak": 4 * 64 / (5 * 4.0), "unit": "lane-steps per CU and clock",
+            "frac": docs_per_s / world * nt * walk_steps / (256 * 2.4e9) / (4 * 64 / (5 * 4.0)),
+            "lds_pipe_peak": 64 / ((256 + 512) / 128.0),
+            "walk_steps_per_tree": walk_steps, "mean_path_nodes_per_tree": visits, "lane_use": visits / walk_steps,
+            "useful_node_visits_per_cu_clock": docs_per_s / world * nt * visits / (256 * 2.4e9),
+            "hbm": {"achieved": n * stride * 4.0 / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": n * stride * 4.0 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "traffic": None,
+            "note": "every row is read from HBM once and walked %d x %.1f steps in LDS: HBM is at a fraction of a percent.  A lane-step = one lane advancing one node "
+                    "(leaves repeat themselves until the deepest tree of the wavefront's eight is done); lds_pipe_peak = 64 lanes / (768 B per wave-step / 128 B per clock); "
+                    "counters: profiles/r04_infer_*" % (nt, walk_steps)},
     }
     if args.cpu_rounds > 0:
         import oracle_ffi as O

@@ -2563,6 +2563,8 @@ struct rl_model {
     EnsTree ens;
     float *d_w = nullptr;
     unsigned long long *d_pack = nullptr;   // packed nodes for k_model_eval_tiled (null when the model does not fit the packing)
+    unsigned char *d_perm = nullptr;        // [tiles][kEvalTreeTile] trees of a tile by descending depth (255 = none): walker wavefront p takes ranks 8 p .. 8 p + 7
+    unsigned char *d_gdepth = nullptr;      // [tiles][kEvalParts] deepest leaf among a walker's trees = its lockstep walk length
     int32_t maxcol = 0;                     // largest column any node reads
 };
 
@@ -2614,18 +2616,28 @@ constexpr int kEvalThreads = kEvalDocs * (kEvalParts + 1), kEvalPrefetch = 8;   
 
 static inline size_t eval_tiled_lds(int cols, int maxn)
 {
-    return (size_t)cols * kEvalDocs * 4 + (size_t)kEvalTreeTile * maxn * 8 + (size_t)2 * kEvalTreeTile * kEvalDocs * 4 + 2 * kEvalTreeTile * 4;
+    return (size_t)cols * kEvalDocs * 4 + (size_t)kEvalTreeTile * maxn * 8 + (size_t)2 * kEvalTreeTile * kEvalDocs * 4 + 2 * kEvalTreeTile * 4 + 2 * (kEvalTreeTile + 8);
 }
 
 // cols = max(row_stride, largest column any node reads + 1)
+//
+// The walk (round 4).  A leaf is packed as a node that loops onto itself: it "reads" column 0 -- no RankLib feature has id 0; the staged tile holds
+// -infinity there -- so `x <= value` is always true and its left-child offset is its own.  A chain step is then the same eight instructions for
+// every node (and, add, ds_read_b32, shift, compare, select, add3, ds_read_b64) with no leaf test and no branch, so the compiler issues the eight
+// chains' feature loads back to back and their node loads back to back: the wavefront waits for LDS twice per step of EIGHT chains instead of
+// twice per chain (the branchy version spent half of its time in those waits: 2.5 walker wavefronts per SIMD cannot hide them).  A walker runs
+// as many steps as its deepest tree has levels; the trees of a tile are dealt to the walkers by depth (perm / gdepth, built with the packing), so
+// shallow trees do not idle behind a deep one.  The accumulator adds the outputs in the ensemble's own order whatever walker produced them.
 __global__ __launch_bounds__(kEvalThreads) void k_model_eval_tiled(const unsigned long long *nodes, const float *w, int MAXN, int nt,
-                                                                   const float *X, int64_t n, int stride, int cols, float *out)
+                                                                   const float *X, int64_t n, int stride, int cols, float *out,
+                                                                   const unsigned char *perm, const unsigned char *gdepth)
 {
     extern __shared__ unsigned char ev_raw[];
     float *sX = (float *)ev_raw;                                               // [cols][kEvalDocs]
     unsigned long long *sT = (unsigned long long *)(sX + (size_t)cols * kEvalDocs);   // [kEvalTreeTile][MAXN]
     float *sO = (float *)(sT + (size_t)kEvalTreeTile * MAXN);                  // [2][kEvalTreeTile][kEvalDocs] leaf outputs (double buffer)
     float *sW = sO + 2 * kEvalTreeTile * kEvalDocs;                            // [2][kEvalTreeTile] tree weights
+    unsigned char *sP = (unsigned char *)(sW + 2 * kEvalTreeTile);             // [2][kEvalTreeTile + 8] the tile's walker assignment and walk lengths
     const int tid = threadIdx.x, doc = tid & (kEvalDocs - 1), part = tid / kEvalDocs;
     const bool walker = part < kEvalParts;
     const int tile_words = kEvalTreeTile * MAXN;                               // <= kEvalThreads * kEvalPrefetch (checked by the host)
@@ -2641,6 +2653,8 @@ __global__ __launch_bounds__(kEvalThreads) void k_model_eval_tiled(const unsigne
         unsigned long long pre[kEvalPrefetch];
 #pragma unroll
         for (int u = 0; u < kEvalPrefetch; u++) { const int e = tid + u * kEvalThreads; pre[u] = (e < min(tile_words, nt * MAXN)) ? nodes[e] : 0ull; }
+        __syncthreads();
+        if (tid < kEvalDocs) sX[tid] = -__builtin_inff();                      // column 0: what a leaf "reads" (after the staging pass wrote the rows' column 0)
         int k = 0, tt_prev = 0;
         for (int t0 = 0; t0 < nt; t0 += kEvalTreeTile, k++) {
             const int tt = min(kEvalTreeTile, nt - t0);
@@ -2649,6 +2663,8 @@ __global__ __launch_bounds__(kEvalThreads) void k_model_eval_tiled(const unsigne
 #pragma unroll
             for (int u = 0; u < kEvalPrefetch; u++) { const int e = tid + u * kEvalThreads; if (e < tile_words) sT[e] = pre[u]; }
             if (tid < tt) sW[cb * kEvalTreeTile + tid] = w[t0 + tid];
+            if (tid < kEvalTreeTile) sP[cb * (kEvalTreeTile + 8) + tid] = perm[(size_t)k * kEvalTreeTile + tid];
+            else if (tid < kEvalTreeTile + kEvalParts) sP[cb * (kEvalTreeTile + 8) + tid] = gdepth[(size_t)k * kEvalParts + (tid - kEvalTreeTile)];
             __syncthreads();
             {   // next tile -> registers (in flight during the walk)
                 const size_t nb = (size_t)(t0 + kEvalTreeTile) * MAXN;
@@ -2657,30 +2673,33 @@ __global__ __launch_bounds__(kEvalThreads) void k_model_eval_tiled(const unsigne
                 for (int u = 0; u < kEvalPrefetch; u++) { const int e = tid + u * kEvalThreads; pre[u] = (e < tile_words && e < left) ? nodes[nb + e] : 0ull; }
             }
             if (walker) {
-                const int g = part * kEvalPer;
-                const int cnt = min(kEvalPer, tt - g);                         // trees of this wavefront in the tile (<= 0: none)
-                if (doc < nd && cnt > 0) {      // kEvalPer chains per lane in lockstep; a chain whose lanes are all on leaves is skipped (execz)
-                    float *so = sO + (size_t)cb * kEvalTreeTile * kEvalDocs + (size_t)g * kEvalDocs + doc;
+                const unsigned char *pp = sP + cb * (kEvalTreeTile + 8);
+                const int depth = __builtin_amdgcn_readfirstlane((int)pp[kEvalTreeTile + part]);      // wave-uniform: a scalar loop bound
+                if (depth > 0) {
+                    float *so = sO + (size_t)cb * kEvalTreeTile * kEvalDocs + doc;
                     const unsigned char *tb[kEvalPer];
                     unsigned long long v[kEvalPer];
+                    int li[kEvalPer];
 #pragma unroll
-                    for (int u = 0; u < kEvalPer; u++) { tb[u] = (const unsigned char *)(sT + (size_t)(g + min(u, cnt - 1)) * MAXN); v[u] = *(const unsigned long long *)tb[u]; }
-                    bool any = true;
-                    while (any) {
-                        any = false;
+                    for (int u = 0; u < kEvalPer; u++) {
+                        li[u] = __builtin_amdgcn_readfirstlane((int)pp[part * kEvalPer + u]);         // 255: no such tree in this (last) tile -- the chain walks tree 0 again, unstored
+                        tb[u] = (const unsigned char *)(sT + (size_t)(li[u] < tt ? li[u] : 0) * MAXN);
+                        v[u] = *(const unsigned long long *)tb[u];
+                    }
+                    for (int step = 0; step < depth; step++) {
+                        float x[kEvalPer];
 #pragma unroll
-                        for (int u = 0; u < kEvalPer; u++) {
-                            const unsigned hi = (unsigned)(v[u] >> 32), co = hi & 0xffffu;
-                            if (co != 0xffffu) {                               // Split.eval: value <= threshold goes left (Split.java:118)
-                                const float x = *(const float *)(sXb + co);
-                                const unsigned off = (hi >> 16) + ((x <= __uint_as_float((unsigned)v[u])) ? 0u : 8u);
-                                v[u] = *(const unsigned long long *)(tb[u] + off);
-                                any = true;
-                            }
+                        for (int u = 0; u < kEvalPer; u++) x[u] = *(const float *)(sXb + ((unsigned)(v[u] >> 32) & 0xffffu));
+#pragma unroll
+                        for (int u = 0; u < kEvalPer; u++) {                   // Split.eval: value <= threshold goes left (Split.java:118); a leaf stays where it is
+                            const unsigned off = (unsigned)(v[u] >> 48) + ((x[u] <= __uint_as_float((unsigned)v[u])) ? 0u : 8u);
+                            v[u] = *(const unsigned long long *)(tb[u] + off);
                         }
                     }
+                    if (doc < nd) {
 #pragma unroll
-                    for (int u = 0; u < kEvalPer; u++) if (u < cnt) so[u * kEvalDocs] = __uint_as_float((unsigned)v[u]);
+                        for (int u = 0; u < kEvalPer; u++) if (li[u] < tt) so[li[u] * kEvalDocs] = __uint_as_float((unsigned)v[u]);
+                    }
                 }
             } else if (k > 0 && doc < nd) {                                    // accumulate the previous tile while this one is walked
                 const float *po = sO + (size_t)(cb ^ 1) * kEvalTreeTile * kEvalDocs + doc, *pw = sW + (cb ^ 1) * kEvalTreeTile;
@@ -2744,31 +2763,54 @@ int rl_model_from_text(const char *text, int32_t device, rl_model **out)
         m->maxcol = maxcol;
         bool ok = nt > 0 && (size_t)m->maxn * 8 < 0x10000 && (size_t)(maxcol + 1) * kEvalDocs * 4 < 0xffff &&
                   (size_t)kEvalTreeTile * m->maxn <= (size_t)kEvalThreads * kEvalPrefetch;
-        for (int32_t f : m->features) ok = ok && f >= 0;
+        for (int32_t f : m->features) ok = ok && f >= 1;        // column 0 is what a packed leaf reads (no RankLib feature has id 0: learning/DataPoint.java:33)
         if (ok) {
-            std::vector<unsigned long long> pk(en, 0xffffull << 32);
-            std::vector<int> order, newid;
+            std::vector<unsigned long long> pk(en, 0ull);           // (padding: a leaf at offset 0 with value +0.0)
+            std::vector<int> order, newid, lvl;
+            std::vector<int> tdepth(nt, 0);
             for (size_t i = 0; i < nt && ok; i++) {
                 const HostTree &t = m->trees[i];
-                order.assign(1, 0); newid.assign(t.n_nodes, -1); newid[0] = 0;
+                order.assign(1, 0); newid.assign(t.n_nodes, -1); newid[0] = 0; lvl.assign(1, 0);
                 for (size_t h = 0; h < order.size(); h++) {
                     const int j = order[h];
                     if (t.feature[j] == -1) continue;
-                    if (t.left[j] < 0 || t.right[j] < 0 || t.left[j] >= t.n_nodes || t.right[j] >= t.n_nodes) { ok = false; break; }
-                    newid[t.left[j]] = (int)order.size(); order.push_back(t.left[j]);
-                    newid[t.right[j]] = (int)order.size(); order.push_back(t.right[j]);
+                    if (t.left[j] < 0 || t.right[j] < 0 || t.left[j] >= t.n_nodes || t.right[j] >= t.n_nodes || (int)order.size() + 2 > t.n_nodes) { ok = false; break; }
+                    newid[t.left[j]] = (int)order.size(); order.push_back(t.left[j]); lvl.push_back(lvl[h] + 1);
+                    newid[t.right[j]] = (int)order.size(); order.push_back(t.right[j]); lvl.push_back(lvl[h] + 1);
+                    tdepth[i] = std::max(tdepth[i], lvl[h] + 1);
                 }
                 for (size_t h = 0; h < order.size() && ok; h++) {
                     const int j = order[h];
                     const bool leaf = t.feature[j] == -1;
                     uint32_t bits; const float fv = leaf ? t.output[j] : t.threshold[j];
                     memcpy(&bits, &fv, 4);
-                    const unsigned long long co = leaf ? 0xffffull : (unsigned long long)t.feature[j] * kEvalDocs * 4;
-                    const unsigned long long lo = leaf ? 0ull : (unsigned long long)newid[t.left[j]] * 8;
+                    if (leaf && std::isnan(fv)) { ok = false; break; }       // a leaf loops through `-inf <= value`: NaN outputs take the generic kernel
+                    // leaf: reads column 0 (-infinity in the staged tile) and its left child is itself
+                    const unsigned long long co = leaf ? 0ull : (unsigned long long)t.feature[j] * kEvalDocs * 4;
+                    const unsigned long long lo = leaf ? (unsigned long long)h * 8 : (unsigned long long)newid[t.left[j]] * 8;
                     pk[i * m->maxn + h] = (unsigned long long)bits | (co << 32) | (lo << 48);
                 }
+                if (tdepth[i] > 250) ok = false;
             }
             if (ok) {
+                // the trees of a tile go to the walker wavefronts by descending depth (stable), eight each
+                const size_t ntl = (nt + kEvalTreeTile - 1) / kEvalTreeTile;
+                std::vector<unsigned char> pm(ntl * kEvalTreeTile, 255), gd(ntl * kEvalParts, 0);
+                std::vector<int> idx;
+                for (size_t tl = 0; tl < ntl; tl++) {
+                    const size_t t0 = tl * kEvalTreeTile, tt = std::min<size_t>(kEvalTreeTile, nt - t0);
+                    idx.resize(tt);
+                    for (size_t q = 0; q < tt; q++) idx[q] = (int)q;
+                    std::stable_sort(idx.begin(), idx.end(), [&](int a2, int b2) { return tdepth[t0 + a2] > tdepth[t0 + b2]; });
+                    for (size_t q = 0; q < tt; q++) {
+                        pm[tl * kEvalTreeTile + q] = (unsigned char)idx[q];
+                        unsigned char &g = gd[tl * kEvalParts + q / kEvalPer];
+                        g = std::max<unsigned char>(g, (unsigned char)std::max(tdepth[t0 + idx[q]], 1));      // (a single-leaf tree still stores its output: one step)
+                    }
+                }
+                RL_HIP(m->pool.alloc(&m->d_perm, pm.size())); RL_HIP(m->pool.alloc(&m->d_gdepth, gd.size()));
+                RL_HIP(hipMemcpy(m->d_perm, pm.data(), pm.size(), hipMemcpyHostToDevice));
+                RL_HIP(hipMemcpy(m->d_gdepth, gd.data(), gd.size(), hipMemcpyHostToDevice));
                 RL_HIP(m->pool.alloc(&m->d_pack, en));
                 RL_HIP(hipMemcpy(m->d_pack, pk.data(), en * 8, hipMemcpyHostToDevice));
                 RL_HIP(hipFuncSetAttribute((const void *)k_model_eval_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2809,7 +2851,8 @@ static int model_eval_launch(rl_model *m, const float *dX, int64_t n_docs, int32
     if (m->d_pack && lds <= (size_t)160 * 1024 && !force_generic) {
         const int64_t tiles = (n_docs + kEvalDocs - 1) / kEvalDocs;
         hipLaunchKernelGGL(k_model_eval_tiled, dim3((unsigned)std::min<int64_t>(tiles, 256 * 256)), dim3(kEvalThreads), lds, s,
-                           (const unsigned long long *)m->d_pack, (const float *)m->d_w, m->maxn, (int)m->trees.size(), dX, n_docs, row_stride, cols, dO);
+                           (const unsigned long long *)m->d_pack, (const float *)m->d_w, m->maxn, (int)m->trees.size(), dX, n_docs, row_stride, cols, dO,
+                           (const unsigned char *)m->d_perm, (const unsigned char *)m->d_gdepth);
     } else {
         hipLaunchKernelGGL(k_model_eval, dim3((unsigned)std::min<int64_t>(8192, (n_docs + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, m->ens,
                            (const float *)m->d_w, m->maxn, (int)m->trees.size(), dX, n_docs, row_stride, dO);

@@ -141,3 +141,54 @@ def test_fullsize_oracle_parity(shape, rounds, strict):
              t_or / rounds, os.cpu_count() or 8))
     print("[fullsize parity] lazy tie-break: %s (resolutions, nodes, chain nodes, chain documents)" % g.array("TIE_STATS").tolist())
     assert stats.get("plateau", 0) == 0
+
+
+def test_ensemble_eval_10k_trees_1m_rows():
+    """BASELINE.json configs[4] in the -m gpu suite at 1/100 of its rows: a 10 000-tree, 31-leaf ensemble (100 trained rounds tiled, as bench.py
+    --workload infer builds it) scores 1 000 003 device-resident rows (a partial last tile).  The oracle's Ensemble.eval (learning/tree/
+    Ensemble.java:110-116, Split.java:115-125) on samples of the first, a middle and the last rows must give the same bits; a second pass over the
+    same rows must give the same bits again; rows with NaN and +-Infinity cells (NaN compares false: right child, Split.java:118) included."""
+    import torch
+    F, L, rounds, nt = 136, 31, 100, 10000
+    X, lab, qoff = synth.make_dataset(60000, F, "mslr")
+    g = N.Trainer(n_trees=rounds, n_leaves=L)
+    g.set_train(X, lab, qoff)
+    g.init()
+    g.boost_rounds_async(rounds)
+    g.sync()
+    g.finish()
+    trees = [g.get_tree(i).trimmed() for i in range(rounds)]
+    text = g.model_text()
+    head, body = text.split("<ensemble>\n", 1)
+    blocks = [b.split(">", 1)[1] for b in body.rsplit("</ensemble>", 1)[0].split("\t</tree>\n")[:-1]]
+    assert len(blocks) == rounds
+    text = head + "<ensemble>\n" + "".join("\t<tree id=\"%d\" weight=\"0.1\">%s\t</tree>\n" % (i + 1, blocks[i % rounds]) for i in range(nt)) + "</ensemble>\n"
+    m = N.Model(text)
+    assert m.num_trees() == nt
+    n, stride = 1000003, F + 1
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    dX = torch.empty((n, stride), dtype=torch.float32, device="cuda")
+    for a in range(0, n, 1 << 18):
+        b = min(n, a + (1 << 18))
+        u = torch.rand((b - a, stride), generator=gen, device="cuda")
+        k = torch.arange(stride, device="cuda") % 4
+        dX[a:b] = torch.where(k == 1, torch.floor(u * 21.0), torch.where(k == 2, u, torch.where(k == 3, torch.exp(4.0 * u), torch.where(u < 0.7, torch.zeros_like(u), u))))
+    dX[:, 0] = 0
+    dX[5, 3] = float("nan"); dX[6, 7] = float("inf"); dX[7, 9] = float("-inf"); dX[n - 2, 17] = float("nan")
+    dO = torch.zeros(n, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    t0 = time.time()
+    m.predict_device(dX.data_ptr(), n, stride, dO.data_ptr())
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    first = dO.cpu().numpy().copy()
+    dO.zero_()
+    m.predict_device(dX.data_ptr(), n, stride, dO.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(first.view(np.uint32), dO.cpu().numpy().view(np.uint32)), "two passes over the same rows differ"
+    all_trees = [trees[i % rounds] for i in range(nt)]
+    threads = os.cpu_count() or 8
+    for a, b in ((0, 1500), (n // 2 - 700, n // 2 + 700), (n - 1500, n)):
+        ref = O.eval_flat_model(all_trees, dX[a:b].cpu().numpy(), n_threads=threads)
+        assert np.array_equal(ref.view(np.uint32), first[a:b].view(np.uint32)), (a, b)
+    print("\n[infer] %d trees x %d rows: %.2f s first pass (%.1f M docs/s incl. launch), 4 400 sampled rows equal the oracle's Ensemble.eval" % (nt, n, dt, n / dt / 1e6))
