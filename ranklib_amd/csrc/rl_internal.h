@@ -109,6 +109,7 @@ struct Ctx {
     int32_t sub_child;            // features per block of the child-node histogram passes (16, or 8 / 4: RLHIP_SUB_CHILD)
     int32_t hist_nt;              // threads per block of the child-node histogram passes (256 / 512 / 1024; launch_hist)
     int32_t node_div, node_min, node_chunk;   // child-node histograms: target chunks per node, smallest / largest chunk (see chunk_docs)
+    const int32_t *live_nthr;      // [n_live] thresholds of live[i] (saves k_hist_finish a dependent load)
     int32_t n_live; const int32_t *live;   // unsharded runs: features with more than one distinct value (the others can never split); k_hist_finish
                                   // is launched over these only (a third of the Yahoo-shape columns are empty)
     int32_t limb_words;           // sharded runs: int64 words per bin in the all-reduced histogram: 3 = (sum >> 44, sum & (2^44-1), count),

@@ -1604,15 +1604,16 @@ int rl_init(rl_trainer *t)
     RL_HIP(hipMemsetAsync(d_thr, 0, (size_t)F * TS * sizeof(float), s));
     RL_HIP(hipMemcpy2DAsync(d_thr, TS * sizeof(float), thr0, TS0 * sizeof(float), TS * sizeof(float), F, hipMemcpyDeviceToDevice, s));
     c.thr = d_thr; c.nthr = d_nthr;
-    c.live = nullptr; c.n_live = F;
+    c.live = nullptr; c.live_nthr = nullptr; c.n_live = F;
     if (!t->dist) {       // features that can split at all (> 1 distinct value <=> more than the value + Float.MAX_VALUE thresholds)
-        std::vector<int32_t> live;
-        for (int f = 0; f < F; f++) if (h_nthr[f] > 2) live.push_back(f);
-        if (live.empty()) live.push_back(0);
-        int32_t *d_live = nullptr;
-        RL_HIP(t->pool.alloc(&d_live, live.size()));
+        std::vector<int32_t> live, live_n;
+        for (int f = 0; f < F; f++) if (h_nthr[f] > 2) { live.push_back(f); live_n.push_back(h_nthr[f]); }
+        if (live.empty()) { live.push_back(0); live_n.push_back(h_nthr[0]); }
+        int32_t *d_live = nullptr, *d_live_n = nullptr;
+        RL_HIP(t->pool.alloc(&d_live, live.size())); RL_HIP(t->pool.alloc(&d_live_n, live.size()));
         RL_HIP(hipMemcpy(d_live, live.data(), live.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        c.live = d_live; c.n_live = (int32_t)live.size();
+        RL_HIP(hipMemcpy(d_live_n, live_n.data(), live_n.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        c.live = d_live; c.live_nthr = d_live_n; c.n_live = (int32_t)live.size();
     }
     {   // more finish blocks a step than the fused kernel keeps resident (5 a CU): the per-feature work and the bookkeeping become two launches
         const char *e = getenv("RLHIP_FIN_SPLIT");
