@@ -537,6 +537,19 @@ def main():
                                                      "transport": "host callbacks over gloo (test aid)" if os.environ.get("RLHIP_BENCH_TRANSPORT") == "gloo" else "RCCL",
                                                      "note": "payload handed to the transport by this rank per round: histogram limbs per growth step (all-reduce); lambda / weight of the "
                                                              "leaves this rank owns, from the ranks that hold their documents (all-to-all); per-query metric values and leaf tables (all-gather)"}
+        # DESIGN.md 6's latency model of a sharded round next to what this run measured: the day several GPUs run this line the model is tested.
+        # Constants are the one-GPU c2 measurements of round 4 (profiles/r04*): per-document work scales with the shard, a growth step keeps its
+        # launch / latency floor and gains one all-reduce (assumed 20 us + bytes at 40 GB/s effective ring bandwidth per rank over xGMI).
+        steps_tree = float(gs[0]) / max(int(gs[3]), 1)
+        share = float(X.shape[0]) / 3.77e6
+        ar_bytes = ds[1] / max(ds[0], 1.0)
+        t_doc = (0.42 + 0.14 + 0.25 + 0.07 + 0.04) * share            # lambdas, ranking, root pass, score update, quantisation (ms at 3.77 M documents)
+        t_step = steps_tree * (0.060 + 0.045 * share + 0.020 + ar_bytes / 40e9 * 1e3)      # latency floor of 5 launches + the shard's histogram work + collective
+        t_leaf = 0.30 * max(share, 0.6 / world + 0.4 * share) + 0.15    # float chains of the owned leaves (the largest leaf has one owner) + the exchange and its host hand-over
+        out["config"]["scaling_model"] = {"modelled_ms_per_round": t_doc + t_step + t_leaf, "measured_ms_per_round": 1000.0 * elapsed / args.steps,
+                                          "growth_steps_per_tree": steps_tree, "allreduce_bytes_per_call": ar_bytes,
+                                          "note": "modelled = per-document kernels x shard share + growth steps x (launch floor + shard's histogram work + one all-reduce) + leaf sums; "
+                                                  "constants from the one-GPU c2 profile (DESIGN.md 6); never fitted to a multi-GPU run"}
         if not weak:
             out["config"]["scaling_note"] = ("strong scaling of %d documents is latency-bound: a 31-leaf tree is a chain of ~11 dependent growth steps, each with one "
                                              "all-reduce when sharded, whatever the shard size (DESIGN.md 6); --scaling weak keeps the documents per GPU fixed" % n_docs)

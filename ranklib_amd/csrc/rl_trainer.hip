@@ -88,6 +88,7 @@ struct rl_trainer {
     Ctx ctx;
     EnsTree ens;
     int32_t L_eff = 0;          // leaf budget in force: n_leaves, or floor(N / min_leaf_support) for -leaf -1
+    int32_t *d_tie_flag = nullptr;                    // sharded tie-break: the ranks' common out-of-memory decision (resolve_ties)
     int64_t sp_entries = 0; int32_t sp_cols = 0;      // sparse-column path of the root pass (rl_csc.inc)
     int32_t cr_groups = 0; double cr_entries = 0, cr_overflow = 0;          // compact rows (groups that use them; of the child passes (k_compact_rows): entries outside the mode bins, rows that need the dense fallback
     double err_max = 16.0;      // ERRScorer.MAX when the trainer was created (rl_set_err_max)
@@ -521,13 +522,18 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool de
     const auto t_begin = std::chrono::steady_clock::now();
     struct TieScope { DistBackend *d; TieScope(DistBackend *d_) : d(d_) { if (d) d->tie_scope = true; } ~TieScope() { if (d) d->tie_scope = false; } } tie_scope(t->dist.get());
     // small reads come back through one pinned buffer (a pageable copy costs tens of microseconds each)
-    const size_t pin_need = sizeof(TreeState) + (size_t)(c.NC + 2) * sizeof(NodeRec) + (size_t)kTieMaxChain * c.F * 4 + ((size_t)1 << 20);
-    if (t->tie_pin_cap < pin_need) {
+    // The pinned buffer grows with what a resolution needs (nothing in flight reads it when it is asked to: every use is copy, synchronise, memcpy):
+    // a batch of deferred nodes of a tree with hundreds of leaves, or of wide data with many tied features, is not a reason to stop training
+    auto ensure_pin = [&](size_t bytes) -> int {
+        if (t->tie_pin_cap >= bytes) return RL_OK;
         if (t->tie_pin) (void)hipHostFree(t->tie_pin);
         t->tie_pin = nullptr; t->tie_pin_cap = 0;
-        if (hipHostMalloc(&t->tie_pin, pin_need, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return fail(RL_ERR_HIP, "tie-break: no pinned host memory"); }
-        t->tie_pin_cap = pin_need;
-    }
+        const size_t want = bytes + bytes / 4;
+        if (hipHostMalloc(&t->tie_pin, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return fail(RL_ERR_HIP, "tie-break: no pinned host memory"); }
+        t->tie_pin_cap = want;
+        return RL_OK;
+    };
+    { int rcp = ensure_pin(sizeof(TreeState) + (size_t)(c.NC + 2) * sizeof(NodeRec) + (size_t)kTieMaxChain * c.F * 4 + ((size_t)1 << 20)); if (rcp) return rcp; }
     char *pin = (char *)t->tie_pin;
     RL_HIP(hipMemcpyAsync(pin, c.st, sizeof(TreeState), hipMemcpyDeviceToHost, s));
     RL_HIP(hipMemcpyAsync(pin + sizeof(TreeState), c.nodes, (size_t)c.NC * sizeof(NodeRec), hipMemcpyDeviceToHost, s));
@@ -593,7 +599,8 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool de
     const int nA = (int)an.size();
     const bool sharded = t->dist && t->n_ranks > 1;       // the members of a chain node are spread over the ranks: their values are gathered (below)
     const int R = sharded ? t->n_ranks : 1;
-    if (nA > kTieMaxChain) return fail(RL_ERR_UNSUPPORTED, "tie-break: derivation chain of " + std::to_string(nA) + " nodes");
+    // (the host tables above are complete: the pinned buffer may move now.  need[] and the chain nodes come back through it in stage 1)
+    { int rcp = ensure_pin((size_t)nA * c.F * sizeof(int32_t) + (size_t)nA * sizeof(TieNode) + (size_t)std::max(R, 1) * nA * sizeof(int32_t) + ((size_t)1 << 20)); if (rcp) return rcp; pin = (char *)t->tie_pin; }
     size_t list_total = 0, u_total = 0;
     std::vector<long long> u0((size_t)nA);
     int maxcnt = 1;
@@ -689,7 +696,7 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool de
     if (sharded) walk = false;                // the walk reads this rank's documents only; rl_init keeps the tie-break off for sharded runs with huge tables
     std::vector<int32_t> cnts((size_t)npairs * c.TS);
     if (!walk) {       // cumulative bin counts of the pairs (exact): where every bin's run starts in the sorted values
-        if (cnts.size() * sizeof(int32_t) > t->tie_pin_cap) return fail(RL_ERR_UNSUPPORTED, "tie-break: too many (chain node, feature) pairs");
+        { int rcp = ensure_pin(cnts.size() * sizeof(int32_t) + 4096); if (rcp) return rcp; pin = (char *)t->tie_pin; }
         for (int p = 0; p < npairs; p++)
             RL_HIP(hipMemcpyAsync(pin + (size_t)p * c.TS * sizeof(int32_t), c.cum_cnt + ((size_t)an[pairs[p].a].node * c.F + pairs[p].f) * c.TS, (size_t)c.TS * sizeof(int32_t),
                                   hipMemcpyDeviceToHost, s));
@@ -723,14 +730,35 @@ static int resolve_ties(rl_trainer *t, size_t fin_lds, int nodes_in_lds, bool de
     for (int p = 0; p < npairs; p++) l_m += (size_t)lcnt[pairs[p].a];
     const size_t spec_bytes = (m_total + 64) * 2 + (sharded ? (l_u + u_total + 64) * 8 + (l_m + m_total + 64) * 2 + (size_t)(R + 1) * nA * 4 : 0) + (size_t)(nA + 2 * npairs + 8) * 8 + v_total * 8 + (size_t)npairs * tiles_max * c.TS * 4 + (size_t)nwin * (16 + 16 + 4) + (size_t)nchunks * (4 + 16 + 8 + 8 * kSpW + 4) +
                               (size_t)nch * (16 + 8 + 8 + sizeof(TieChain)) + (size_t)npairs * sizeof(TiePair) + (size_t)(nwin + nchunks) * 4 + 64 * 256;
-    if (!walk && fixed_bytes + spec_bytes + ((size_t)1 << 20) > t->tie_cap) {
+    {
         // the arena has to grow: it moves, so stage 1 runs again in the new one (and later calls ask for this much up front)
-        t->tie_hint = fixed_bytes + spec_bytes + ((size_t)1 << 20);
-        if (tie_arena_reserve(t, t->tie_hint)) {      // no room for the contiguous chains: the literal walk in a minimal arena
-            walk = true;
-            if (tie_arena_reserve(t, fixed_bytes + ((size_t)1 << 20))) return fail(RL_ERR_HIP, "tie-break: out of device memory");
+        const bool grow = !walk && fixed_bytes + spec_bytes + ((size_t)1 << 20) > t->tie_cap;
+        int oom = 0;
+        if (grow) {
+            t->tie_hint = fixed_bytes + spec_bytes + ((size_t)1 << 20);
+            if (tie_arena_reserve(t, t->tie_hint)) oom = 1;
         }
-        int rc1 = stage1(); if (rc1) return rc1;
+        if (sharded) {
+            // spec_bytes and the free memory differ from rank to rank, the exchange below does not: the out-of-memory decision is taken by ALL ranks
+            // (a rank that fell back to the walk on its own would leave the others waiting in the all-to-all -- and the walk sums its own documents
+            // only).  One 4-byte all-reduce per resolution of a sharded run.
+            if (!t->d_tie_flag) RL_HIP(t->pool.alloc(&t->d_tie_flag, (size_t)4));
+            int32_t *d_oom = t->d_tie_flag;
+            RL_HIP(hipMemcpyAsync(d_oom, &oom, sizeof(oom), hipMemcpyHostToDevice, s));
+            int rcd = t->dist->allreduce(d_oom, 1, DT_I32, OP_MAX, s);
+            if (rcd) return rcd;
+            int32_t any = 0;
+            RL_HIP(hipMemcpyAsync(&any, d_oom, sizeof(any), hipMemcpyDeviceToHost, s));
+            RL_HIP(hipStreamSynchronize(s));
+            if (any) return fail(RL_ERR_HIP, "tie-break: out of device memory on a rank of the job (the sharded tie-break needs the gathered chains on every rank)");
+            if (grow) { int rc1 = stage1(); if (rc1) return rc1; }
+        } else if (grow) {
+            if (oom) {      // no room for the contiguous chains: the literal walk in a minimal arena
+                walk = true;
+                if (tie_arena_reserve(t, fixed_bytes + ((size_t)1 << 20))) return fail(RL_ERR_HIP, "tie-break: out of device memory");
+            }
+            int rc1 = stage1(); if (rc1) return rc1;
+        }
     }
     if (walk) {
         RL_HIP(hipMemsetAsync(a.jbin, 0, (size_t)nA * c.F * c.TS * sizeof(double), s));

@@ -30,8 +30,12 @@ def main():
     Xs, ls, qs = D.shard(X, lab, qoff, rank, world)
     tr = D.TorchHostTransport()
     estop = 1 if "valid" in opts else 100
+    # "perdev": one rank per GPU (a multi-GPU box: the real RCCL data path over xGMI); otherwise every rank shares device 0
+    device = int(os.environ.get("LOCAL_RANK", "0")) if "perdev" in opts else 0
+    if "perdev" in opts:
+        torch.cuda.set_device(device)
     g = N.Trainer(n_trees=rounds, n_leaves=-1 if "leafm1" in opts else leaves, ranker=ranker, metric=metric, metric_k=k, early_stop_rounds=estop,
-                  min_leaf_support=40 if "leafm1" in opts else 1)
+                  min_leaf_support=40 if "leafm1" in opts else 1, device=device)
     g.set_train(Xs, ls, qs)
     if "qrel" in opts:       # -qrel: every rank passes the judgments of ITS lists (tests/test_gpu_dist.py external_judgments is the same rule)
         qb, qe = D.partition_queries(qoff, world)[rank]

@@ -158,3 +158,19 @@ def test_equal_lambdas_on_opposite_sides_are_caught_by_the_check():
     trees, ties, st, _ = run(X, lab, qoff, 3, 8)
     assert ties == 0, st
     assert st[9] > 0, st                                              # at least the first tree was grown twice
+
+
+@pytest.mark.parametrize("leaves,mls,n_docs,n_feat", [(1200, 1, 60000, 17), (-1, 4, 9000, 24)])
+def test_wide_trees_resolve_every_deferred_tie_without_a_limit(leaves, mls, n_docs, n_feat):
+    """Trees of a thousand leaves (and -leaf -1 with a small minimum leaf support): the deferred batch at the end of a tree holds hundreds of right
+    children with plateau ties, i.e. hundreds of chain nodes and (chain node, feature) pairs in ONE resolution.  The pinned read-back buffer grows
+    with the batch (it used to be sized for 512 chain nodes and the round failed with RL_ERR_UNSUPPORTED beyond: ADVICE r03); the stored
+    (feature, threshold) pairs are the oracle's."""
+    X, lab, qoff = synth.make_dataset(n_docs, n_feat, "mslr", seed_offset=23)
+    X = X.copy()
+    X[:, ::2] = np.floor(X[:, ::2] * 6.0)            # low-cardinality columns: small nodes tie all the time
+    trees, ties, st, _ = run(X, lab, qoff, 2, leaves, min_leaf_support=mls)
+    assert ties == 0
+    n_leaves = int((trees[0]["feature"] == -1).sum())
+    assert n_leaves >= 600, n_leaves
+    assert st[0] > 0 and st[2] > 512, st              # resolutions ran, over more chain nodes than the old fixed capacity
