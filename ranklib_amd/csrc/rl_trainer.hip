@@ -1748,7 +1748,23 @@ int rl_init(rl_trainer *t)
         // dense fallback; built when at least half of the groups do.  RLHIP_CROWS=0 / 1 forces them off / on for every group
         const char *e = getenv("RLHIP_CROWS");
         const int force = e ? atoi(e) : -1;
-        if (force != 0 && TS <= kHistLdsStride && c.sub == 16) {
+        bool maybe = force == 1;
+        if (force < 0 && TS <= kHistLdsStride && c.sub == 16) {
+            // cheap look first (the exact root counts are on the device already): dense data -- more than 5 cells a row outside the mode bins on
+            // average -- never builds the rows (a gigabyte of transient memory and 8 ms at the MSLR-WEB30K shape)
+            std::vector<int32_t> hc((size_t)F * TS), hm((size_t)F);
+            RL_HIP(hipStreamSynchronize(s));
+            RL_HIP(hipMemcpy(hc.data(), c.cum_cnt, hc.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            RL_HIP(hipMemcpy(hm.data(), d_mode, hm.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            double cells = 0;
+            const double n_all = (double)hc[(size_t)h_nthr[0] - 1];           // documents over all ranks (the counts are all-reduced when sharded)
+            for (int f = 0; f < F; f++) {
+                const int m = hm[f];
+                cells += n_all - ((double)hc[(size_t)f * TS + m] - (m > 0 ? (double)hc[(size_t)f * TS + m - 1] : 0.0));
+            }
+            maybe = cells <= 5.0 * n_all * (double)c.numFG;
+        }
+        if (maybe && TS <= kHistLdsStride && c.sub == 16) {
             unsigned long long *d_st = nullptr; uint4 *d_cr = nullptr;
             const int crs = (c.numFG + 7) & ~7;           // rows start on 128-byte lines
             RL_HIP(t->pool.alloc(&d_st, (size_t)2 * c.numFG)); RL_HIP(hipMemsetAsync(d_st, 0, (size_t)2 * c.numFG * sizeof(unsigned long long), s));
