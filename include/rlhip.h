@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define RLHIP_ABI_VERSION 4
+#define RLHIP_ABI_VERSION 5
 
 enum {
     RL_OK = 0,
@@ -86,7 +86,8 @@ typedef struct rl_model rl_model;       /* opaque: a loaded ensemble for scoring
 typedef struct {
     int32_t n_trees;            /* LambdaMART.nTrees            default 1000 */
     int32_t n_leaves;           /* LambdaMART.nTreeLeaves       default 10   */
-    int32_t n_threshold;        /* LambdaMART.nThreshold        default 256 (-1: every distinct value) */
+    int32_t n_threshold;        /* LambdaMART.nThreshold        default 256 (-1: every distinct value; any size: tables beyond 4095 entries run as
+                                   several histogram features, rl_hist_features) */
     int32_t min_leaf_support;   /* LambdaMART.minLeafSupport    default 1    */
     int32_t early_stop_rounds;  /* LambdaMART.nRoundToStopEarly default 100  */
     float   learning_rate;      /* LambdaMART.learningRate      default 0.1F (a Java float) */
@@ -135,7 +136,8 @@ int  rl_create(const rl_params *p, rl_trainer **out);
 void rl_destroy(rl_trainer *t);
 
 /* Training set.  X is row-major [n_docs][n_features], already resolved through
- * DataPoint.getFeatureValue(feature_ids[f]) (missing / NaN -> 0: learning/DenseDataPoint.java:21-32).
+ * DataPoint.getFeatureValue(feature_ids[f]) (missing / NaN -> 0: learning/DenseDataPoint.java:21-32); a NaN left in X is RL_ERR_INVALID at
+ * rl_init, +-Infinity is a value like any other (binned as learning/tree/LambdaMART.java:108-149 and FeatureHistogram.java:88-107 bin it).
  * qoff[n_queries+1]: docs of query q are qoff[q]..qoff[q+1]-1 (file order, learning/RankList.java).
  * feature_ids[n_features]: the IDs written into the model (Ranker.features); NULL => 1..n_features.
  * qkey[n_queries]: optional; equal keys == equal qid strings (idealGains cache quirk,
@@ -305,6 +307,11 @@ int rl_debug_exp(const double *x, int32_t n, double *out_fast, double *out_ref);
  * sum of segment s.  stats (may be null): int32[4] = segments evaluated, window misses repaired, segments finished serially, 0. */
 int rl_debug_float_chain(int32_t device, const double *x, int64_t n, const int64_t *seg_start, int32_t n_seg, float *out, int32_t *stats);
 int rl_bin_stride(const rl_trainer *t, int32_t *stride);
+/* Histogram features of an initialised trainer and the column (0-based position in feature_ids) behind each.  Equal to the data set's features
+ * unless a threshold table has more than 4095 entries (-tc -1 on a column with that many distinct values, or -tc N > 4095: learning/tree/
+ * LambdaMART.java:135-149): such a feature is split into runs of 4094 thresholds and RL_ARR_NBINS / THRESHOLDS / BINS /
+ * ROOT_* are shaped by THIS count.  columns may be NULL; at most cap entries are written. */
+int rl_hist_features(const rl_trainer *t, int32_t *n, int32_t *columns, int32_t cap);
 int rl_quant_exponent(const rl_trainer *t, int32_t *e);   /* q = rint(lambda * 2^e) in the last round */
 int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes);
 

@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "rl_set_train", "rl_set_validation", "rl_set_rows", "rl_set_external_judgments", "rl_init", "rl_boost_round", "rl_boost_rounds_async", "rl_sync",
     "rl_finish", "rl_num_trees", "rl_get_tree", "rl_get_round_metrics", "rl_best_validation", "rl_predict",
     "rl_model_to_text", "rl_model_from_text", "rl_model_destroy", "rl_model_num_trees", "rl_model_features",
-    "rl_model_predict", "rl_model_predict_device", "rl_dist_unique_id", "rl_dist_init", "rl_dist_init_callback", "rl_dist_stats", "rl_bin_stride", "rl_quant_exponent", "rl_get_array", "rl_debug_exp", "rl_debug_float_chain",
+    "rl_model_predict", "rl_model_predict_device", "rl_dist_unique_id", "rl_dist_init", "rl_dist_init_callback", "rl_dist_stats", "rl_bin_stride", "rl_hist_features", "rl_quant_exponent", "rl_get_array", "rl_debug_exp", "rl_debug_float_chain",
     "rl_letor_parse", "rl_letor_info", "rl_letor_arrays", "rl_letor_rows", "rl_letor_destroy",
     "rl_get_timing", "rl_reset_timing", "rl_set_timing_flags", "rl_debug_membench", "rl_set_err_max", "rl_tree_capacity",
 ]
@@ -106,6 +106,7 @@ def lib():
     L.rl_dist_stats.argtypes = [vp, vp]
     L.rl_dist_init_callback.argtypes = [vp, i32, i32, HOST_ALLREDUCE, HOST_ALLGATHER, HOST_ALLTOALLV, vp]
     L.rl_bin_stride.argtypes = [vp, C.POINTER(i32)]
+    L.rl_hist_features.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), i32]
     L.rl_quant_exponent.argtypes = [vp, C.POINTER(i32)]
     L.rl_get_array.argtypes = [vp, i32, vp, i64]
     L.rl_debug_exp.argtypes = [vp, i32, vp, vp]
@@ -411,15 +412,24 @@ class Trainer:
         check(lib().rl_quant_exponent(self.h, C.byref(e)))
         return e.value
 
+    def hist_features(self):
+        """(number of histogram features, column behind each): the data set's features unless a threshold table has more than 4095 entries (rlhip.h)"""
+        n = C.c_int32(0)
+        check(lib().rl_hist_features(self.h, C.byref(n), None, 0))
+        cols = np.zeros(n.value, np.int32)
+        check(lib().rl_hist_features(self.h, C.byref(n), cols.ctypes.data_as(C.POINTER(C.c_int32)), n.value))
+        return n.value, cols
+
     def array(self, name):
         which = ARR[name]
         TS = self.bin_stride()
+        F_hist = self.hist_features()[0] if name in ("NBINS", "THRESHOLDS", "BINS", "ROOT_COUNT", "ROOT_SUM", "ROOT_SUM_FIXED", "ROOT_SUM_JAVA") else self.F
         shapes = {
             "LAMBDA": ((self.N,), np.float64), "WEIGHT": ((self.N,), np.float64), "SCORE": ((self.N,), np.float64),
-            "VALID_SCORE": ((self.Nv,), np.float64), "NBINS": ((self.F,), np.int32),
-            "THRESHOLDS": ((self.F, TS), np.float32), "BINS": ((self.F, self.N), np.uint16),
-            "ROOT_COUNT": ((self.F, TS), np.int32), "ROOT_SUM": ((self.F, TS), np.float64), "ROOT_SUM_JAVA": ((self.F, TS), np.float64),
-            "QUANT": ((self.N,), np.int64), "ROOT_SUM_FIXED": ((self.F, TS, 2), np.int64),
+            "VALID_SCORE": ((self.Nv,), np.float64), "NBINS": ((F_hist,), np.int32),
+            "THRESHOLDS": ((F_hist, TS), np.float32), "BINS": ((F_hist, self.N), np.uint16),
+            "ROOT_COUNT": ((F_hist, TS), np.int32), "ROOT_SUM": ((F_hist, TS), np.float64), "ROOT_SUM_JAVA": ((F_hist, TS), np.float64),
+            "QUANT": ((self.N,), np.int64), "ROOT_SUM_FIXED": ((F_hist, TS, 2), np.int64),
             "NDCG_PER_QUERY": ((self.Q,), np.float64), "CHAIN_STATS": ((6,), np.int32), "GROW_STATS": ((4,), np.int32), "GROW_DOCS": ((4,), np.int64), "SPARSE_INFO": ((8,), np.int64), "PHASE_CLOCKS": ((64, 32), np.int64), "BLOCK_TRACE": ((64, 3, 2048, 8), np.int64), "STEP_LOG": ((8 + 8 * 8192,), np.int32), "TIE_STATS": ((10,), np.int64), "CHAIN_MISS": ((2, self.cap + 1), np.int32),
         }
         shape, dt = shapes[name]

@@ -143,6 +143,8 @@ struct Ctx {
     const float *thr;       // [F][TS]
     const int32_t *nthr;    // [F]
     const int32_t *feature_ids;
+    const int32_t *vcol;    // [F] column of the row matrix behind histogram feature f (null = identity): a real feature whose threshold table has more than
+                            // 4095 entries is several virtual features (rl_init)
     const float *labels;    // [N]
     const int32_t *qoff;    // [Q+1]
     const double *ideal0, *ideal1;  // [Q] ideal DCG used by swapChange in round 0 / later (NDCGScorer cache quirk)

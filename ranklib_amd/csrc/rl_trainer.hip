@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <limits>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -78,6 +79,7 @@ struct rl_trainer {
     rl_params p;
     int32_t F = 0;
     std::vector<int32_t> feature_ids;
+    std::vector<int32_t> vcol;         // histogram (virtual) feature -> column of the row matrix; empty = identity (rl_init: tables beyond 4095 entries)
     DataSet tr, va;
     bool has_train = false, has_valid = false, inited = false, finished = false;
     hipStream_t stream = nullptr;
@@ -1227,7 +1229,7 @@ static int enqueue_round(rl_trainer *t)
     } else enqueue_metric_mean(t, t->tr.d_ndcg, t->tr.Q, c.round_metric + 2 * (size_t)m);
     if (t->has_valid) {   // :228-237
         hipLaunchKernelGGL(k_valid_update, dim3(std::min<int64_t>(4096, (t->va.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
-                           t->ens, c.MAXN, m, (const float *)t->va.d_X, (int)t->va.N, c.F, c.lr, t->va.d_scores);
+                           t->ens, c.MAXN, m, (const float *)t->va.d_X, (int)t->va.N, t->F, c.lr, t->va.d_scores);
         rc = launch_rank(t, t->va, t->va.d_scores, t->va.d_ndcg, false);
         if (rc != RL_OK) return rc;
         if (t->dist) {      // every rank holds a shard of the validation lists: the float mean runs over all of them in list order
@@ -1379,8 +1381,8 @@ int rl_create(const rl_params *p, rl_trainer **out)
     if (p->n_trees < 1) return fail(RL_ERR_INVALID, "n_trees must be >= 1");
     if (p->n_leaves < 1 && p->n_leaves != -1) return fail(RL_ERR_INVALID, "n_leaves must be >= 1, or -1 for trees limited by min_leaf_support only");
     if (p->min_leaf_support < 1) return fail(RL_ERR_INVALID, "min_leaf_support must be >= 1");
-    if (p->n_threshold != -1 && (p->n_threshold < 1 || p->n_threshold + 1 > kMaxBins))
-        return fail(RL_ERR_UNSUPPORTED, "n_threshold must be -1 or in [1," + std::to_string(kMaxBins - 1) + "]");
+    if (p->n_threshold != -1 && (p->n_threshold < 1 || p->n_threshold > (1 << 24)))
+        return fail(RL_ERR_UNSUPPORTED, "n_threshold must be -1 or in [1, 2^24]");
     if (p->flags & ~(RL_FLAG_TIMING | RL_FLAG_TIMING_NODES | RL_FLAG_SERIAL_CHAIN | RL_FLAG_JAVA_ORDER | RL_FLAG_FIRST_TIE)) return fail(RL_ERR_INVALID, "unknown bit in rl_params.flags");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -1523,7 +1525,8 @@ int rl_init(rl_trainer *t)
     RL_HIP(hipDeviceSynchronize());      // uploads of rl_set_* went through the null stream; t->stream is non-blocking
     Ctx &c = t->ctx;
     hipStream_t s = t->stream;
-    const int N = (int)t->tr.N, F = t->F;
+    const int N = (int)t->tr.N;
+    int F = t->F;                        // columns of the row matrix until the threshold tables are built, histogram features after (rl_init: virtual features)
     const int Npad = (N + 127) / 128 * 128;
     // -leaf -1 (RegressionTree.java:72 `nodes == -1`): growth ends when no leaf can be split any more.  Every leaf holds at least
     // min_leaf_support documents, so a tree has at most floor(N / mls) leaves -- and with exactly that many none is left with 2 * mls
@@ -1578,7 +1581,7 @@ int rl_init(rl_trainer *t)
     hipLaunchKernelGGL(k_transpose, dim3((N + 31) / 32, (F + 31) / 32), dim3(kThreads), 0, s, (const float *)t->tr.d_X, Xt, N, F, Npad);
     const int nT = t->p.n_threshold;
     FeatStats fs;
-    fs.limit = (nT == -1) ? kMaxBins - 1 : nT;
+    fs.limit = (nT == -1 || nT > kMaxBins - 1) ? kMaxBins - 1 : nT;        // the device's distinct-value sets hold up to 4 095 values; larger tables are built on the host (below)
     fs.HS = next_pow2(2 * (fs.limit + 2));
     RL_HIP(t->pool.alloc(&fs.minkey, (size_t)F)); RL_HIP(t->pool.alloc(&fs.maxkey, (size_t)F));
     RL_HIP(t->pool.alloc(&fs.set, (size_t)F * fs.HS)); RL_HIP(t->pool.alloc(&fs.nset, (size_t)F));
@@ -1612,25 +1615,99 @@ int rl_init(rl_trainer *t)
     RL_HIP(hipStreamSynchronize(s));
     RL_HIP(hipMemcpy(h_over.data(), fs.overflow, F * sizeof(int32_t), hipMemcpyDeviceToHost));
     RL_HIP(hipMemcpy(&h_bad, fs.bad, sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (h_bad) return fail(RL_ERR_INVALID, "non-finite feature value (resolve NaN to 0 as DataPoint.getFeatureValue does; +-Infinity is not supported)");
-    if (nT == -1)
-        for (int f = 0; f < F; f++)
-            if (h_over[f]) return fail(RL_ERR_UNSUPPORTED, "-tc -1 with more than " + std::to_string(kMaxBins - 1) + " distinct values in a feature");
+    if (h_bad) return fail(RL_ERR_INVALID, "NaN feature value (resolve NaN to 0 as DataPoint.getFeatureValue does)");
+    const bool want_big = (nT == -1 || nT > kMaxBins - 1);         // tables of more than 4 095 entries are possible
     const int TS0 = fs.limit + 1;
     float *thr0 = nullptr; int32_t *d_nthr = nullptr;
     RL_HIP(t->pool.alloc(&thr0, (size_t)F * TS0)); RL_HIP(t->pool.alloc(&d_nthr, (size_t)F));
-    hipLaunchKernelGGL(k_thresholds, dim3(F), dim3(kThreads), fs.HS * sizeof(uint32_t), s, fs, nT == -1 ? fs.limit : nT, TS0, thr0, d_nthr);
+    hipLaunchKernelGGL(k_thresholds, dim3(F), dim3(kThreads), fs.HS * sizeof(uint32_t), s, fs, want_big ? fs.limit : nT, TS0, thr0, d_nthr);
     RL_HIP(hipGetLastError());
     std::vector<int32_t> h_nthr(F);
     RL_HIP(hipStreamSynchronize(s));
     RL_HIP(hipMemcpy(h_nthr.data(), d_nthr, F * sizeof(int32_t), hipMemcpyDeviceToHost));
-    int TS = 2;
-    for (int f = 0; f < F; f++) TS = std::max(TS, h_nthr[f]);
-    c.TS = TS;
+    // ---- threshold tables of more than 4 095 entries (-tc -1 on a column with that many distinct values, or -tc N > 4095: learning/tree/
+    // LambdaMART.java:135-149 has no limit).  The histogram kernels keep a feature's bins in LDS, so such a REAL feature becomes several VIRTUAL
+    // features, one per run of 4 094 consecutive thresholds: virtual feature r has the table [thr[r W], .., thr[r W + W - 1], MAX_VALUE] over the same
+    // column.  "Smallest t with value <= table[t]" then clamps a document's real bin into the run -- documents below it join the run's first bin,
+    // documents above it the MAX_VALUE bin -- so the run's cumulative histogram is the real feature's cumulative histogram on its thresholds, every
+    // real candidate is a candidate of exactly one virtual feature, in the Java's scan order, and the MAX_VALUE bin of a run that is not the last
+    // never splits (nothing on its right).  Everything after this block sees F = the number of virtual features; trees are exported with the real
+    // column (Ctx::vcol).  The large tables are built on the host (sort + unique of the column).
+    std::vector<std::vector<float>> big((size_t)F);
+    bool any_big = false;
+    if (want_big) {
+        std::vector<float> colv((size_t)N);
+        for (int f = 0; f < F; f++) {
+            if (!h_over[f]) continue;
+            RL_HIP(hipMemcpy(colv.data(), Xt + (size_t)f * Npad, (size_t)N * sizeof(float), hipMemcpyDeviceToHost));
+            float fmax = -std::numeric_limits<float>::infinity(), fmin = 3.4028234663852886e38f;       // :114-115
+            for (auto &v : colv) { if (v == 0.f) v = 0.f; if (fmax < v) fmax = v; if (fmin > v) fmin = v; }      // (-0.0 folded as on the device)
+            std::vector<float> vals(colv);
+            std::sort(vals.begin(), vals.end());
+            vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+            std::vector<float> &tab = big[f];
+            if (nT == -1 || (long long)vals.size() <= (long long)nT) { tab = vals; tab.push_back(3.4028234663852886e38f); }      // :135-140
+            else {                                                                                                              // :141-149
+                const float step = fabsf(fmax - fmin) / (float)nT;
+                tab.resize((size_t)nT + 1);
+                tab[0] = fmin;
+                for (int j = 1; j < nT; j++) tab[j] = tab[j - 1] + step;
+                tab[nT] = 3.4028234663852886e38f;
+            }
+            any_big = true;
+        }
+    }
     float *d_thr = nullptr;
-    RL_HIP(t->pool.alloc(&d_thr, (size_t)F * TS));
-    RL_HIP(hipMemsetAsync(d_thr, 0, (size_t)F * TS * sizeof(float), s));
-    RL_HIP(hipMemcpy2DAsync(d_thr, TS * sizeof(float), thr0, TS0 * sizeof(float), TS * sizeof(float), F, hipMemcpyDeviceToDevice, s));
+    int TS = 2;
+    t->vcol.clear();
+    c.vcol = nullptr;
+    if (!any_big) {
+        for (int f = 0; f < F; f++) TS = std::max(TS, h_nthr[f]);
+        c.TS = TS;
+        RL_HIP(t->pool.alloc(&d_thr, (size_t)F * TS));
+        RL_HIP(hipMemsetAsync(d_thr, 0, (size_t)F * TS * sizeof(float), s));
+        RL_HIP(hipMemcpy2DAsync(d_thr, TS * sizeof(float), thr0, TS0 * sizeof(float), TS * sizeof(float), F, hipMemcpyDeviceToDevice, s));
+    } else {
+        if (t->dist) return fail(RL_ERR_UNSUPPORTED, "a threshold table of more than 4095 entries with multi-GPU training (the distinct values of a column would have to be merged over the ranks)");
+        if (t->p.flags & RL_FLAG_JAVA_ORDER) return fail(RL_ERR_UNSUPPORTED, "a threshold table of more than 4095 entries with RL_FLAG_JAVA_ORDER (the Java's prefix over ALL bins of a feature is one f64 chain)");
+        if (c.fs_size != F) return fail(RL_ERR_UNSUPPORTED, "a threshold table of more than 4095 entries with feature sampling");
+        std::vector<float> h_thr0((size_t)F * TS0);
+        RL_HIP(hipMemcpy(h_thr0.data(), thr0, h_thr0.size() * sizeof(float), hipMemcpyDeviceToHost));
+        constexpr int W = kMaxBins - 2;
+        std::vector<std::vector<float>> rows;
+        for (int f = 0; f < F; f++) {
+            const float *tab = big[f].empty() ? h_thr0.data() + (size_t)f * TS0 : big[f].data();
+            const long long T = big[f].empty() ? h_nthr[f] : (long long)big[f].size();
+            if (T <= kMaxBins - 1) { rows.emplace_back(tab, tab + T); t->vcol.push_back(f); continue; }
+            for (long long r0 = 0; r0 < T; r0 += W) {
+                const long long e1 = std::min<long long>(r0 + W, T);
+                std::vector<float> row(tab + r0, tab + e1);
+                if (e1 < T) row.push_back(3.4028234663852886e38f);
+                rows.push_back(std::move(row)); t->vcol.push_back(f);
+            }
+        }
+        if (rows.size() > (size_t)(1 << 20)) return fail(RL_ERR_UNSUPPORTED, "threshold tables of more than 2^32 entries in total");
+        F = (int)rows.size();
+        for (auto &r : rows) TS = std::max(TS, (int)r.size());
+        c.TS = TS;
+        std::vector<float> h_thr((size_t)F * TS, 0.f);
+        h_nthr.assign((size_t)F, 0);
+        for (int v = 0; v < F; v++) { memcpy(h_thr.data() + (size_t)v * TS, rows[v].data(), rows[v].size() * sizeof(float)); h_nthr[v] = (int32_t)rows[v].size(); }
+        t->pool.release(d_nthr); d_nthr = nullptr;
+        RL_HIP(t->pool.alloc(&d_thr, (size_t)F * TS)); RL_HIP(t->pool.alloc(&d_nthr, (size_t)F));
+        RL_HIP(hipMemcpy(d_thr, h_thr.data(), h_thr.size() * sizeof(float), hipMemcpyHostToDevice));
+        RL_HIP(hipMemcpy(d_nthr, h_nthr.data(), (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice));
+        int32_t *d_vcol = nullptr;
+        RL_HIP(t->pool.alloc(&d_vcol, (size_t)F));
+        RL_HIP(hipMemcpy(d_vcol, t->vcol.data(), (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice));
+        c.vcol = d_vcol;
+        c.F = F; c.fs_size = F;
+        c.node_div = std::max(4, std::min(12, (int)(12.0 * std::sqrt(136.0 / (double)std::max(F, 1)) + 0.5)));
+        if (const char *e = getenv("RLHIP_NODE_DIV")) c.node_div = std::max(1, atoi(e));
+        // exact ties: the first candidate in the Java's scan order.  The lazy re-decision needs the Java's own f64 prefix over ALL bins of a real feature,
+        // which a run of a split table does not hold (its first bin is a merged sum)
+        c.tie_on = 0;
+    }
     c.thr = d_thr; c.nthr = d_nthr;
     c.live = nullptr; c.live_nthr = nullptr; c.n_live = F;
     if (!t->dist) {       // features that can split at all (> 1 distinct value <=> more than the value + Float.MAX_VALUE thresholds)
@@ -1693,7 +1770,7 @@ int rl_init(rl_trainer *t)
         RL_HIP(hipMemsetAsync(c.jbin, 0, (size_t)kSpec * F * TS * sizeof(double), s));
     }
     hipLaunchKernelGGL(k_binning, dim3(F, slices), dim3(kThreads), (size_t)TS * 8, s, (const float *)Xt, N, Npad, TS, (const float *)d_thr,
-                       (const int32_t *)d_nthr, d_bins, d_gbins, c.cum_cnt);
+                       (const int32_t *)d_nthr, d_bins, d_gbins, c.cum_cnt, c.vcol);
     if (t->dist) { int rcd = t->dist->allreduce(c.cum_cnt, (size_t)F * TS, DT_I32, OP_SUM, s); if (rcd) return rcd; }
     {
         uint16_t *d_dbins = nullptr;
@@ -1935,7 +2012,11 @@ int rl_init(rl_trainer *t)
     c.scores = t->tr.d_scores; c.ndcg_q = t->tr.d_ndcg;
     int32_t *d_fid = nullptr;
     RL_HIP(t->pool.alloc(&d_fid, (size_t)F));
-    RL_HIP(hipMemcpy(d_fid, t->feature_ids.data(), F * sizeof(int32_t), hipMemcpyHostToDevice));
+    {   // (ids of the histogram features: a virtual feature carries its real column's id)
+        std::vector<int32_t> ids((size_t)F);
+        for (int v = 0; v < F; v++) ids[v] = t->feature_ids[t->vcol.empty() ? v : t->vcol[v]];
+        RL_HIP(hipMemcpy(d_fid, ids.data(), F * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     c.feature_ids = d_fid;
 
     // ---- per-round state -------------------------------------------------------------------------
@@ -2332,6 +2413,15 @@ int rl_dist_init_callback(rl_trainer *t, int32_t rank, int32_t n_ranks, rl_host_
 }
 
 // ---- introspection -------------------------------------------------------------------------------
+int rl_hist_features(const rl_trainer *t, int32_t *n, int32_t *columns, int32_t cap)
+{
+    if (check_trainer(t) || !n) return fail(RL_ERR_INVALID, "null argument");
+    if (!t->inited) return fail(RL_ERR_STATE, "rl_init has not been called");
+    *n = t->ctx.F;
+    if (columns) for (int32_t v = 0; v < t->ctx.F && v < cap; v++) columns[v] = t->vcol.empty() ? v : t->vcol[v];
+    return RL_OK;
+}
+
 int rl_bin_stride(const rl_trainer *t, int32_t *stride)
 {
     if (check_trainer(t)) return RL_ERR_INVALID;

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "librlhip.so does not export %s" % name
     assert sorted(N.ABI_SYMBOLS) == declared
-    assert L.rl_abi_version() == 4
+    assert L.rl_abi_version() == 5
 
 
 def test_no_cpu_fallback_without_device(gpu_available):

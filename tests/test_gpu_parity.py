@@ -651,11 +651,10 @@ def test_edge_cases_match_the_oracle(name):
 @pytest.mark.gpu
 def test_bad_inputs_are_rejected_with_ranklib_style_errors():
     X, lab, qoff = make(200, 3, "ns", 9)
-    for bad, msg in ((np.inf, "finite"), (np.nan, "NaN")):
-        Xb = X.copy(); Xb[17, 1] = bad
-        g = N.Trainer(n_trees=1, n_leaves=4)
-        with pytest.raises(N.RankLibError):
-            g.set_train(Xb, lab, qoff); g.init()
+    Xb = X.copy(); Xb[17, 1] = np.nan                      # NaN never reaches the trainer in the reference (DataPoint.getFeatureValue resolves it to 0);
+    g = N.Trainer(n_trees=1, n_leaves=4)                    # +-Infinity is a value like any other since round 4 (test_infinite_feature_values_...)
+    with pytest.raises(N.RankLibError):
+        g.set_train(Xb, lab, qoff); g.init()
     g = N.Trainer(n_trees=1, n_leaves=4)
     with pytest.raises(N.RankLibError):
         g.set_train(X, -lab - 1, qoff)                      # negative labels (learning/DataPoint.java:71-73)
@@ -709,6 +708,83 @@ def test_sparse_700_feature_shape_matches_the_oracle(mode, monkeypatch):
         for f in np.nonzero(nb > 2)[0][:60]:
             hi, lo = int(fixed[f, nb[f] - 1, 0]), int(fixed[f, nb[f] - 1, 1]) & 0xFFFFFFFFFFFFFFFF
             assert hi * 2 ** 64 + lo == tot, (r, f)
+
+
+def test_infinite_feature_values_are_binned_as_the_reference_bins_them():
+    """+-Infinity in the rows (learning/tree/LambdaMART.java:108-149 accepts them; NaN never reaches the trainer: DataPoint.getFeatureValue).  A table of
+    distinct values holds the infinite value as a value; a 256-step table of a column with maximum +Infinity is [fmin, Inf, .., MAX_VALUE]; one with minimum
+    -Infinity is [-Inf, NaN, .., MAX_VALUE] and every document above -Infinity lands in bin 1 (`value > NaN` never breaks the Java's loop).  Thresholds,
+    bins, counts, trees, scores and Ensemble.eval of the saved model equal the oracle's."""
+    rng = np.random.default_rng(3)
+    X, lab, qoff = make(4000, 8, "mslr", 17)
+    X = X.copy()
+    n = X.shape[0]
+    X[:, 0] = np.floor(rng.random(n) * 9)                         # few distinct values: exact-value thresholds ...
+    X[rng.random(n) < 0.03, 0] = np.inf; X[rng.random(n) < 0.02, 0] = -np.inf      # ... among them +-Infinity
+    X[:, 1] = rng.random(n).astype(np.float32); X[rng.random(n) < 0.05, 1] = np.inf           # > 256 distinct values, maximum +Infinity
+    X[:, 2] = rng.random(n).astype(np.float32); X[rng.random(n) < 0.05, 2] = -np.inf          # minimum -Infinity: NaN thresholds
+    X[:, 3] = rng.random(n).astype(np.float32); X[rng.random(n) < 0.04, 3] = np.inf; X[rng.random(n) < 0.04, 3] = -np.inf
+    o, g = pair(X, lab, qoff, n_trees=4, n_leaves=12)
+    o.init(); g.init()
+    nb, thr, bins, cnt = g.array("NBINS"), g.array("THRESHOLDS"), g.array("BINS"), g.array("ROOT_COUNT")
+    for f in range(8):
+        T = o.n_bins(f)
+        assert nb[f] == T, f
+        assert np.array_equal(thr[f, :T], o.thresholds(f), equal_nan=True), (f, thr[f, :6], o.thresholds(f)[:6])
+        assert np.array_equal(bins[f].astype(np.int32), o.bins(f)), f
+        assert np.array_equal(cnt[f, :T], o.root_count(f)), f
+    assert np.isinf(thr[0, nb[0] - 2]) and np.isnan(thr[2, 1]) and np.isinf(thr[1, 1])
+    for r in range(4):
+        to, tmo, _, _ = o.round()
+        tg, tmg, _, _ = g.boost_round()
+        assert_same_tree(to, tg, X, "round %d" % r)
+        assert np.array_equal(g.array("SCORE").view(np.int64), o.scores().view(np.int64))
+        assert tmo == tmg
+    g.finish()
+    m = N.Model(g.model_text())
+    rows = np.zeros((n, 9), np.float32); rows[:, 1:] = X
+    assert np.array_equal(m.predict_rows(rows).view(np.uint32), o.predict(X).view(np.uint32))
+
+
+@pytest.mark.parametrize("tc", [-1, 6000])
+def test_threshold_tables_beyond_4095_entries_split_into_virtual_features(tc):
+    """-tc -1 on columns with 9 000 distinct values (every distinct value a threshold, learning/tree/LambdaMART.java:135-140) and -tc 6000 (a 6 001-entry
+    step table, :141-149): the reference has no limit on the table size.  A feature whose table exceeds 4 095 entries is histogrammed as several virtual
+    features over runs of 4 094 thresholds (rl_init); the trees name the real feature id and the real threshold, and trees, lambdas, scores, metrics and
+    Ensemble.eval of the saved model equal the oracle's.  Exact ties keep the first candidate in the Java's scan order on such data (no lazy
+    re-decision: the Java's f64 prefix runs over ALL bins of the real feature)."""
+    rng = np.random.default_rng(9)
+    X, lab, qoff = make(9000, 6, "mslr", 29)
+    X = X.copy()
+    n = X.shape[0]
+    X[:, 1] = rng.permutation(n).astype(np.float32) / 7.0        # 9 000 distinct values
+    X[:, 4] = (rng.random(n) * 1e4).astype(np.float32)           # ~9 000 distinct values, another scale
+    X[:, 2] = np.floor(rng.random(n) * 12)                       # an ordinary low-cardinality column in between
+    o, g = pair(X, lab, qoff, n_trees=3, n_leaves=16, n_threshold=tc)
+    o.init(); g.init()
+    nf, cols = g.hist_features()
+    nb, thr = g.array("NBINS"), g.array("THRESHOLDS")
+    assert nf > 6 and sorted(set(cols.tolist())) == list(range(6)) and (np.diff(cols) >= 0).all(), (nf, cols)
+    for f in range(6):                                           # the runs of a real feature, MAX_VALUE catch-alls dropped, are its table
+        runs = [v for v in range(nf) if cols[v] == f]
+        parts = [thr[v, :nb[v] - (1 if v != runs[-1] else 0)] for v in runs]
+        table = np.concatenate(parts)
+        assert len(table) == o.n_bins(f), (f, len(table), o.n_bins(f))
+        assert np.array_equal(table.view(np.uint32), o.thresholds(f).view(np.uint32)), f
+        assert all(nb[v] <= 4095 for v in runs)
+    for r in range(3):
+        to, tmo, _, _ = o.round()
+        tg, tmg, _, _ = g.boost_round()
+        assert np.array_equal(g.array("LAMBDA").view(np.int64), o.lambdas().view(np.int64)), r
+        assert_equivalent(to, tg, X, "round %d" % r)              # (ties may store another member of the tie: first candidate wins here)
+        assert np.array_equal(g.array("SCORE").view(np.int64), o.scores().view(np.int64))
+        assert tmo == tmg
+        tt = tg.trimmed()
+        assert set(tt["feature"][tt["feature"] != -1].tolist()) <= set(range(1, 7))         # real feature ids
+    g.finish()
+    m = N.Model(g.model_text())
+    rows = np.zeros((n, 7), np.float32); rows[:, 1:] = X
+    assert np.array_equal(m.predict_rows(rows).view(np.uint32), g.predict(X).view(np.uint32))
 
 
 @pytest.mark.parametrize("kind,nfeat", [("mslr", 40), ("mixed", 48)])
