@@ -86,6 +86,9 @@ struct rl_trainer {
     // the per-round training metric (a float chain over the queries) is off the critical path of the next round: it runs
     // on a side stream between two events (single-GPU runs without a validation set)
     hipStream_t side = nullptr; hipEvent_t ev_ranked = nullptr, ev_metric = nullptr; bool side_pending = false;
+    // the lambda kernels of the list-length classes are independent: three of them run on streams of their own beside the main one, so that the tail
+    // of one class (its last blocks) overlaps the next class instead of idling the chip (RLHIP_LAMBDA_STREAMS=0: one after the other)
+    hipStream_t lam_s[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev_lam_fork = nullptr, ev_lam_join[3] = {nullptr, nullptr, nullptr}; bool lam_streams = false;
     DevPool pool;
     Ctx ctx;
     EnsTree ens;
@@ -910,11 +913,22 @@ static int enqueue_round(rl_trainer *t)
             auto lds_of = [&](int bt) { return (size_t)c.k * (bt + 8) * 16 + (size_t)c.k * 24 + lambda_fused_extra_bytes(mode, c.k, bt); };
             n_max = 0;
             const DataSet &d = t->tr;
+            // (ls: the stream of this class -- the main one, or one of the three side streams forked below)
+            int lam_used = 0;
+            const bool fork = t->lam_streams && !t->dist;
+            if (fork) { RL_HIP(hipEventRecord(t->ev_lam_fork, s)); }
+            auto lam_stream = [&]() -> hipStream_t {
+                if (!fork || lam_used >= 3) return s;
+                hipStream_t ls = t->lam_s[lam_used++];
+                (void)hipStreamWaitEvent(ls, t->ev_lam_fork, 0);
+                return ls;
+            };
 #define RL_LAUNCH_FUSED(BT, cls)                                                                                                             \
             if (d.n_qcls[cls] > 0) {                                                                                                         \
-                if (mode == 0) hipLaunchKernelGGL((k_lambda_fused<BT, 0>), dim3(d.n_qcls[cls]), dim3(BT), lds_of(BT), s, g, (const int *)d.d_qcls[cls], d.n_qcls[cls]); \
-                else if (mode == 1) hipLaunchKernelGGL((k_lambda_fused<BT, 1>), dim3(d.n_qcls[cls]), dim3(BT), lds_of(BT), s, g, (const int *)d.d_qcls[cls], d.n_qcls[cls]); \
-                else hipLaunchKernelGGL((k_lambda_fused<BT, 2>), dim3(d.n_qcls[cls]), dim3(BT), lds_of(BT), s, g, (const int *)d.d_qcls[cls], d.n_qcls[cls]); \
+                hipStream_t ls = lam_stream();                                                                                               \
+                if (mode == 0) hipLaunchKernelGGL((k_lambda_fused<BT, 0>), dim3(d.n_qcls[cls]), dim3(BT), lds_of(BT), ls, g, (const int *)d.d_qcls[cls], d.n_qcls[cls]); \
+                else if (mode == 1) hipLaunchKernelGGL((k_lambda_fused<BT, 1>), dim3(d.n_qcls[cls]), dim3(BT), lds_of(BT), ls, g, (const int *)d.d_qcls[cls], d.n_qcls[cls]); \
+                else hipLaunchKernelGGL((k_lambda_fused<BT, 2>), dim3(d.n_qcls[cls]), dim3(BT), lds_of(BT), ls, g, (const int *)d.d_qcls[cls], d.n_qcls[cls]); \
                 n_max += d.n_qcls[cls]; g.blockmax = t->d_wmax + n_max;                                                                      \
             }
             if (d.n_qcls[4] > 0 && mode == 0) {
@@ -925,11 +939,13 @@ static int enqueue_round(rl_trainer *t)
             } else {
                 RL_LAUNCH_FUSED(64, 4)          // ERR / MAP: the lists of at most 16 documents take the block-per-query kernel too
             }
-            RL_LAUNCH_FUSED(64, 0)
-            RL_LAUNCH_FUSED(128, 1)
-            RL_LAUNCH_FUSED(192, 2)
+            // longest lists first on the side streams (they take longest per block), the shortest class last on the main stream
             RL_LAUNCH_FUSED(256, 3)
+            RL_LAUNCH_FUSED(192, 2)
+            RL_LAUNCH_FUSED(128, 1)
+            RL_LAUNCH_FUSED(64, 0)
 #undef RL_LAUNCH_FUSED
+            for (int i = 0; i < lam_used; i++) { RL_HIP(hipEventRecord(t->ev_lam_join[i], t->lam_s[i])); RL_HIP(hipStreamWaitEvent(s, t->ev_lam_join[i], 0)); }
         } else {
             const unsigned nb = (unsigned)((c.N + kThreads - 1) / kThreads);
             hipLaunchKernelGGL(k_pair_terms, dim3(nb), dim3(kThreads), 0, s, g);
@@ -1401,6 +1417,11 @@ int rl_create(const rl_params *p, rl_trainer **out)
     RL_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
     RL_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
     RL_HIP(hipEventCreateWithFlags(&t->ev_ranked, hipEventDisableTiming)); RL_HIP(hipEventCreateWithFlags(&t->ev_metric, hipEventDisableTiming));
+    t->lam_streams = !(getenv("RLHIP_LAMBDA_STREAMS") && atoi(getenv("RLHIP_LAMBDA_STREAMS")) == 0);
+    if (t->lam_streams) {
+        RL_HIP(hipEventCreateWithFlags(&t->ev_lam_fork, hipEventDisableTiming));
+        for (int i = 0; i < 3; i++) { RL_HIP(hipStreamCreateWithFlags(&t->lam_s[i], hipStreamNonBlocking)); RL_HIP(hipEventCreateWithFlags(&t->ev_lam_join[i], hipEventDisableTiming)); }
+    }
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 16, kHistLdsStride>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 16, kHistLdsStride>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 16, kHistLdsStride, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
@@ -1450,6 +1471,8 @@ void rl_destroy(rl_trainer *t)
                 t->tie_stalls, t->tie_batches, t->tie_regrown, t->tie_phase_us[0], t->tie_phase_us[1], t->tie_phase_us[2], t->tie_phase_us[3], t->tie_phase_us[4], t->tie_us);
     if (t->stream) { (void)hipStreamSynchronize(t->stream); }
     if (t->side) { (void)hipStreamSynchronize(t->side); (void)hipStreamDestroy(t->side); }
+    if (t->ev_lam_fork) (void)hipEventDestroy(t->ev_lam_fork);
+    for (int i = 0; i < 3; i++) { if (t->ev_lam_join[i]) (void)hipEventDestroy(t->ev_lam_join[i]); if (t->lam_s[i]) (void)hipStreamDestroy(t->lam_s[i]); }
     if (t->ev_ranked) (void)hipEventDestroy(t->ev_ranked);
     if (t->ev_metric) (void)hipEventDestroy(t->ev_metric);
     for (int w = 0; w < RL_KERNEL_COUNT_; w++)
