@@ -976,8 +976,8 @@ static int enqueue_round(rl_trainer *t)
         }
     }
     // the last block of k_hist_finish runs the growth bookkeeping (select_step); node records live in LDS when they fit
-    const int nodes_in_lds = (select_lds_bytes(c.L, c.NC, true, c.F, c.fs_size < c.F) <= 60 * 1024) ? 1 : 0;
-    const size_t fin_lds = std::max((size_t)c.TS * (c.java ? 28 : 20) + 8, select_lds_bytes(c.L, c.NC, nodes_in_lds != 0, c.F, c.fs_size < c.F));
+    const int nodes_in_lds = (select_lds_bytes(c.L, c.NC, true, c.F, c.fs_on != 0) <= 60 * 1024) ? 1 : 0;
+    const size_t fin_lds = std::max((size_t)c.TS * (c.java ? 28 : 20) + 8, select_lds_bytes(c.L, c.NC, nodes_in_lds != 0, c.F, c.fs_on != 0));
     const int jbg = (c.TS + 63) / 64;        // RL_FLAG_JAVA_ORDER: 64-bin groups of k_jhist (+ 1 block for the node totals)
     if (fin_lds > 128 * 1024) return fail(RL_ERR_UNSUPPORTED, "too many features / leaves for the growth bookkeeping in LDS (feature sampling needs 64 bytes per feature)");
     if (t->dist) {
@@ -1577,8 +1577,8 @@ int rl_init(rl_trainer *t)
     // chunks a child node is cut into: every chunk flushes a partial histogram of F x T x 12 bytes that the finish reads back, so wide data wants fewer
     // (measured, rounds/s: c3, 700 columns: 3 / 4 / 6 / 8 / 12 / 16 / 24 -> 542 / 548 / 548 / 549-556 / 534 / 537 / 513; c2, 136 columns: flat from 8 to 32)
     c.node_div = std::max(4, std::min(12, (int)(12.0 * std::sqrt(136.0 / (double)std::max(F, 1)) + 0.5))); c.node_min = kMinChunk;
-    c.fs_size = F; c.seed = t->p.seed;
-    if (t->p.feature_sampling_rate > 0.0f && t->p.feature_sampling_rate < 1.0f) c.fs_size = (int32_t)(t->p.feature_sampling_rate * (float)F);   // :274
+    c.fs_size = F; c.fs_on = 0; c.seed = t->p.seed;
+    if (t->p.feature_sampling_rate > 0.0f && t->p.feature_sampling_rate < 1.0f) { c.fs_size = (int32_t)(t->p.feature_sampling_rate * (float)F); c.fs_on = c.fs_size < F ? 1 : 0; }   // :274
     c.hist_nt = kThreads; c.sub_child = 16;
     if (const char *e = getenv("RLHIP_SUB_CHILD")) { const int v = atoi(e); if (v == 4 || v == 8) c.sub_child = v; }
     if (const char *e = getenv("RLHIP_HIST_NT")) c.hist_nt = atoi(e);
@@ -1693,7 +1693,6 @@ int rl_init(rl_trainer *t)
     } else {
         if (t->dist) return fail(RL_ERR_UNSUPPORTED, "a threshold table of more than 4095 entries with multi-GPU training (the distinct values of a column would have to be merged over the ranks)");
         if (t->p.flags & RL_FLAG_JAVA_ORDER) return fail(RL_ERR_UNSUPPORTED, "a threshold table of more than 4095 entries with RL_FLAG_JAVA_ORDER (the Java's prefix over ALL bins of a feature is one f64 chain)");
-        if (c.fs_size != F) return fail(RL_ERR_UNSUPPORTED, "a threshold table of more than 4095 entries with feature sampling");
         std::vector<float> h_thr0((size_t)F * TS0);
         RL_HIP(hipMemcpy(h_thr0.data(), thr0, h_thr0.size() * sizeof(float), hipMemcpyDeviceToHost));
         constexpr int W = kMaxBins - 2;
@@ -1724,7 +1723,7 @@ int rl_init(rl_trainer *t)
         RL_HIP(t->pool.alloc(&d_vcol, (size_t)F));
         RL_HIP(hipMemcpy(d_vcol, t->vcol.data(), (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice));
         c.vcol = d_vcol;
-        c.F = F; c.fs_size = F;
+        c.F = F; if (!c.fs_on) c.fs_size = F;          // (with feature sampling fs_size stays a number of REAL features: the draw is over columns)
         c.node_div = std::max(4, std::min(12, (int)(12.0 * std::sqrt(136.0 / (double)std::max(F, 1)) + 0.5)));
         if (const char *e = getenv("RLHIP_NODE_DIV")) c.node_div = std::max(1, atoi(e));
         // exact ties: the first candidate in the Java's scan order.  The lazy re-decision needs the Java's own f64 prefix over ALL bins of a real feature,
