@@ -448,10 +448,10 @@ def main():
     if not args.plain:
         try:        # LDS atomic throughput in the histogram kernels' own LDS layout: what "bound by LDS atomics" is a fraction of (rl_debug_membench modes 4..7)
             lds_cal = {}
-            for name, mode in (("conflict_free", 4), ("random_257_bins", 5), ("same_address", 6), ("random_257_bins_plus_count", 7)):
+            for name, mode in (("consecutive_bins", 4), ("random_bins", 5), ("same_address", 6), ("random_bins_plus_count", 7), ("three_32bit_atomics_instead", 8)):
                 ms_l, n_at = N.membench(mode, 4096, 1, 3, local_rank)
                 lds_cal[name] = n_at / (ms_l * 1e-3) / (256 * 2.4e9)
-            lds_cal["unit"] = "64-bit LDS atomics per CU and clock (256 CUs x 2.4 GHz), three 256-thread blocks per CU, 16 x 264 int64 accumulators per block"
+            lds_cal["unit"] = "atomic groups (one 64-bit atomic; + count; or three 32-bit ones) per CU and clock (256 CUs x 2.4 GHz), three 256-thread blocks per CU, 16 x 264 accumulators per block"
         except Exception as ex:       # noqa: BLE001
             sys.stderr.write("LDS atomic calibration failed: %r\n" % (ex,))
             lds_cal = None
@@ -483,7 +483,7 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": per_launch_ms, "launches": int(n_root),
             "layout_bytes_per_launch": N_loc * (((n_feat + 15) // 16) * (18.0 if T_ <= 257 else 32.0) + 8.0),
             "lds_atomics_per_launch": lds_atomics, "lds_atomics_per_cu_clock": root_atoms_clk,
-            "lds_atomics_frac_of_measured_peak": (root_atoms_clk / lds_cal["random_257_bins"]) if (root_atoms_clk and lds_cal) else None,
+            "lds_atomics_frac_of_measured_peak": (root_atoms_clk / lds_cal["random_bins"]) if (root_atoms_clk and lds_cal) else None,
             "note": "algorithmic bytes = N_local*(F*2 B bin ids + 8 B fixed-point lambda) (SURVEY.md 8d, b = 2); layout bytes = what the packed rows hold; HIP events on the library stream",
             "frac_of_measured_read": (achieved / read_gbs) if read_gbs else None,
         }
@@ -513,7 +513,7 @@ def main():
                 "ms_per_round": node["ms_per_round"], "docs_accumulated_per_round": node["docs_per_round"], "algorithmic_bytes_per_round": nb,
                 "frac_of_measured_gather32": (ach / gather_gbs) if gather_gbs else None,
                 "lds_atomics_per_cu_clock": node_atoms_clk,
-                "lds_atomics_frac_of_measured_peak": (node_atoms_clk / lds_cal["random_257_bins_plus_count"]) if (node_atoms_clk and lds_cal) else None,
+                "lds_atomics_frac_of_measured_peak": (node_atoms_clk / lds_cal["random_bins_plus_count"]) if (node_atoms_clk and lds_cal) else None,
                 "traffic_source": ("live: bench.py re-ran itself under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel trace only); bytes = "
                                    "%.1f x FETCH_SIZE + WRITE_SIZE (factors: profiles/r02_fetch_calibration.txt)" % FETCH_FACTOR_GATHER32) if pmc else None,
                 "note": "algorithmic bytes (SURVEY.md 8d) = documents of the accumulated (smaller) children x (F*2 B bin ids + 8 B lambda + 4 B sample id); HIP events around "

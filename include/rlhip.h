@@ -327,10 +327,10 @@ int rl_set_timing_flags(rl_trainer *t, int32_t flags);
  * mode 0 = copy (16 B per lane; reads + writes `bytes`), 1 = streaming read of `bytes`, 2 = streaming write, 3 = 32-byte row
  * gathers through an ascending index list that takes one row in `stride` (the child-node histogram pattern; 32 B row + 4 B
  * index per entry).  avg_ms = mean HIP-event time of `iters` launches, alg_bytes = algorithmic bytes of one launch.
- * Modes 4..7 = LDS atomic throughput in the histogram kernels' own LDS layout (three 256-thread blocks per CU, 16 rows of 264 int64
- * accumulators): 4 conflict-free, 5 a random bin of 257 per lane, 6 one bin per wavefront (same address), 7 = 5 plus the 32-bit count atomic
- * of the child passes; `bytes` = 64-bit atomics per thread, alg_bytes returns the 64-bit atomics of one launch (the calibration
- * behind bench.py's lds_atomics_frac_of_measured_peak). */
+ * Modes 4..9 = LDS atomic throughput in the histogram kernels' own LDS layout (three 256-thread blocks per CU, 16 rows of 264 int64
+ * accumulators): 4 consecutive bins per wavefront, 5 a random bin of 256 per lane, 6 one bin per wavefront (same address), 7 = 5 plus the
+ * 32-bit count atomic of the child passes, 8 three 32-bit atomics instead of one 64-bit one, 9 one 32-bit atomic; `bytes` = atomic groups per
+ * thread, alg_bytes returns the groups of one launch (the calibration behind bench.py's lds_atomics_frac_of_measured_peak). */
 int rl_debug_membench(int32_t device, int32_t mode, int64_t bytes, int32_t stride, int32_t iters, double *avg_ms, double *alg_bytes);
 int rl_reset_timing(rl_trainer *t);
 

@@ -213,7 +213,7 @@ def set_err_max(max_gain):
 
 def membench(mode, nbytes, stride=1, iters=10, device=0):
     """rl_debug_membench: (avg ms per launch, algorithmic bytes per launch); mode: 0 copy, 1 read, 2 write, 3 32-byte row gather;
-    4..7 LDS atomics (conflict-free / random 257 bins / same address / random + count): nbytes = atomics per thread, returns (ms, atomics per launch)"""
+    4..9 LDS atomics (consecutive bins / random bins / same address / random + count / three 32-bit / one 32-bit): nbytes = atomic groups per thread, returns (ms, groups per launch)"""
     ms, b = C.c_double(0), C.c_double(0)
     check(lib().rl_debug_membench(device, mode, nbytes, stride, iters, C.byref(ms), C.byref(b)))
     return ms.value, b.value

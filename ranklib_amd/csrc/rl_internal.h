@@ -114,6 +114,7 @@ struct Ctx {
                                   // is launched over these only (a third of the Yahoo-shape columns are empty)
     int32_t limb_words;           // sharded runs: int64 words per bin in the all-reduced histogram: 3 = (sum >> 44, sum & (2^44-1), count),
                                   // 2 = ((sum >> 44) << 32 | count, low limb) when the data set has fewer than 2^25 documents
+    const int32_t *fcol;          // [F] feature sampling: the real column whose key feature f carries; bit 31 set on the later runs of a split threshold table
     int32_t fs_on;                // feature sampling is active (fs_size real features are drawn per split attempt)
     int32_t fs_size;              // features a split attempt looks at: F, or (int)(rate * F) with feature sampling (Random Forests)
     unsigned long long seed;      // rl_params.seed

@@ -2034,6 +2034,17 @@ int rl_init(rl_trainer *t)
     c.scores = t->tr.d_scores; c.ndcg_q = t->tr.d_ndcg;
     int32_t *d_fid = nullptr;
     RL_HIP(t->pool.alloc(&d_fid, (size_t)F));
+    {   // feature sampling draws REAL features: the column behind every histogram feature, the later runs of a split table marked (half_wave_best_feature)
+        std::vector<int32_t> fc((size_t)F);
+        for (int v = 0; v < F; v++) {
+            const int col = t->vcol.empty() ? v : t->vcol[v];
+            fc[v] = (v > 0 && !t->vcol.empty() && t->vcol[v - 1] == col) ? (int32_t)((uint32_t)col | 0x80000000u) : col;
+        }
+        int32_t *d_fc = nullptr;
+        RL_HIP(t->pool.alloc(&d_fc, (size_t)F));
+        RL_HIP(hipMemcpy(d_fc, fc.data(), (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice));
+        c.fcol = d_fc;
+    }
     {   // (ids of the histogram features: a virtual feature carries its real column's id)
         std::vector<int32_t> ids((size_t)F);
         for (int v = 0; v < F; v++) ids[v] = t->feature_ids[t->vcol.empty() ? v : t->vcol[v]];
@@ -2614,7 +2625,7 @@ int rl_debug_float_chain(int32_t device, const double *x, int64_t n, const int64
 
 int rl_debug_membench(int32_t device, int32_t mode, int64_t bytes, int32_t stride, int32_t iters, double *avg_ms, double *alg_bytes)
 {
-    if (!avg_ms || bytes < 4096 || iters < 1 || mode < 0 || mode > 7 || (mode == 3 && stride < 1)) return fail(RL_ERR_INVALID, "bad argument");
+    if (!avg_ms || bytes < 4096 || iters < 1 || mode < 0 || mode > 9 || (mode == 3 && stride < 1)) return fail(RL_ERR_INVALID, "bad argument");
     RL_HIP(hipSetDevice(device));
     if (mode >= 4) {
         // LDS atomics (k_mb_lds_atomic): `bytes` = atomics per thread (rounded to 16), `stride` unused; alg_bytes returns the 64-bit atomics of one launch
