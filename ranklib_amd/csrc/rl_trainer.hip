@@ -1128,7 +1128,7 @@ static int enqueue_round(rl_trainer *t)
             if (c.jmap) hipLaunchKernelGGL(k_jhist2, dim3(c.n_live + 1, kSpec), dim3(kJ2Threads), 0, s, c, 0, c.jmap, c.jinv, c.jone);
             else hipLaunchKernelGGL(k_jhist, dim3(c.n_live, jbg + 2, kSpec), dim3(64), 0, s, c, 0, jbg);
             hipLaunchKernelGGL((k_hist_finish<false, false, true>), dim3(c.n_live, kSpec), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
-        } else if (t->fin_split) {
+        } else if (t->fin_split || !nodes_in_lds) {       // (wide data; or node records that do not fit the LDS: the fused kernel has no path for them)
             hipLaunchKernelGGL(k_hist_finish_wide, dim3(c.n_live, kSpec), dim3(kFinWideThreads), (size_t)c.TS * 20 + 8, s, c);
             hipLaunchKernelGGL(k_select, dim3(1), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
         } else hipLaunchKernelGGL((k_hist_finish<false, false>), dim3(c.n_live, kSpec), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
