@@ -32,4 +32,5 @@ for step in range(64):
     a = [r[k] - r[k - 1] for k in range(1, 8)]
     b = [r[k] - r[k - 1] for k in range(9, 14)]
     print("%4d  " % step + "  ".join("%9.2f" % v for v in a) + " | " + "  ".join("%9.2f" % v for v in b) + " | %9.2f  %9.2f" % (r[8] - r[7], r[13] - r[0]) +
-          " | select entry -> state copied %.2f, -> records reduced %.2f" % (r[8] - r[14], r[15] - r[8]))
+          " | select entry -> state copied %.2f, -> records reduced %.2f" % (r[8] - r[14], r[15] - r[8]) +
+          " (prefetch issued %.2f, share reduced %.2f, half wave %.2f, tie pass %.2f, stored %.2f)" % (r[16] - r[8], r[17] - r[16], r[18] - r[17], r[19] - r[18], r[15] - r[19]))

@@ -25,6 +25,8 @@ g.boost_rounds_async(tree + 1)
 g.sync()
 clk = g.array("PHASE_CLOCKS").astype(np.float64) * 0.01          # us
 tr = g.array("BLOCK_TRACE").astype(np.float64) * 0.01
+if os.environ.get("RLHIP_TRACE_DUMP"):                   # raw stamps [step][kernel][block][stamp] for offline analysis
+    np.save(os.environ["RLHIP_TRACE_DUMP"], tr.astype(np.float32) - np.float32(0) if False else (tr - tr[tr > 0].min()).astype(np.float32))
 print("%s, tree %d: per growth step, microseconds" % (shape, tree))
 print("step | part: gap  span   med   max    n | hist: gap  span   med   max    n | finish: gap  span   med   max    n | select tail | step total")
 prev_end = None
@@ -56,9 +58,10 @@ if rows:
 
 # phase stamps inside the blocks (median over the working blocks of the step, microseconds since the block's entry)
 names = {0: ["slot table", "idx + bins loaded", "ballots + sync", "look-back done", "stores issued", "", "exit"],
-         1: ["slot + modes", "LDS zeroed", "first ids", "loop done", "totals", "", "exit"]}
-for k in (0, 1):
-    print("kernel %d (%s): median stamp since block entry, by step" % (k, "partition" if k == 0 else "child histogram"))
+         1: ["slot + modes", "LDS zeroed", "first ids", "loop done", "totals", "", "exit"],
+         2: ["step tables", "chunk sums", "mode bin + prefix", "gain scan", "block best + ties", "", "published"]}
+for k in (0, 1, 2):
+    print("kernel %d (%s): median stamp since block entry, by step" % (k, ["partition", "child histogram", "finish"][k]))
     print("step " + " ".join("%-18s" % n for n in names[k] if n))
     for s_ in range(64):
         b = tr[s_, k]
