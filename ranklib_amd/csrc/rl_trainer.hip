@@ -304,7 +304,7 @@ static int alloc_chain(rl_trainer *t, ChainBufs &b, int maxseg, int A, int64_t n
     b.cap_chunks = b.cap_tiles + maxseg + 2;
     b.cap_n = std::max<int64_t>(n, b.cap_chunks);
     // stitch tables in LDS: first-level groups of `group` chunks (the smaller the group, the shorter the chain of dependent loads)
-    b.group = 8;
+    b.group = kChainBlock;
     while (chain_stitch_lds(b) > 152 * 1024) {
         b.group *= 2;
         if (b.group > 65536) return fail(RL_ERR_UNSUPPORTED, "data set too large for the float-chain stitch kernel");
@@ -318,6 +318,7 @@ static int alloc_chain(rl_trainer *t, ChainBufs &b, int maxseg, int A, int64_t n
     RL_HIP(t->pool.alloc(&b.drift2, (size_t)A * b.cap_chunks));
     RL_HIP(t->pool.alloc(&b.gkey, (size_t)A * b.cap_chunks)); RL_HIP(t->pool.alloc(&b.gkey2, (size_t)A * b.cap_chunks));
     RL_HIP(t->pool.alloc(&b.R, (size_t)A * b.cap_chunks * kChainW));
+    RL_HIP(t->pool.alloc(&b.comp0, (size_t)A * (b.cap_chunks / kChainBlock + 1) * kChainW));
     RL_HIP(t->pool.alloc(&b.result, (size_t)A * maxseg)); RL_HIP(t->pool.alloc(&b.miss, (size_t)A * maxseg));
     RL_HIP(t->pool.alloc(&b.st_status, (size_t)A * maxseg)); RL_HIP(t->pool.alloc(&b.st_chunk, (size_t)A * maxseg));
     RL_HIP(t->pool.alloc(&b.st_key, (size_t)A * maxseg)); RL_HIP(t->pool.alloc(&b.st_delta, (size_t)A * maxseg));
@@ -370,7 +371,9 @@ static void enqueue_chain(rl_trainer *t, const ChainBufs &b, const ChainSource &
     // before the last one it enqueued and leaves the remaining repair passes (near-empty launches) away once nothing is open
     const unsigned long long seq = ++t->chain_seq;
     bool hint = b.h_progress != nullptr && t->step_ahead > 0, clean = false;
+    const dim3 cgrid((unsigned)((b.cap_chunks / kChainBlock + kThreads / 64) / (kThreads / 64)), b.A);       // one wavefront per block of kChainBlock chunks
     hipLaunchKernelGGL(k_chain_tables<false>, tgrid, dim3(kThreads), 0, s, b, 0);
+    hipLaunchKernelGGL(k_chain_compose, cgrid, dim3(kThreads), 0, s, b, 0);
     hipLaunchKernelGGL(k_chain_stitch, dim3(b.maxseg, b.A), dim3(kScanThreads), lds, s, b, 0, seq << 16);
     // With the hint the host sees every stitch's outcome before it enqueues the next repair pass, so it repairs for as long as a segment is open
     // (a chain of tens of millions of elements needs a pass per window of 8192 chunks and one per window miss; the serial finish of a chain
@@ -385,6 +388,7 @@ static void enqueue_chain(rl_trainer *t, const ChainBufs &b, const ChainSource &
         hipLaunchKernelGGL(k_chain_pass1<true>, p1grid, dim3(kThreads), 0, s, b);
         hipLaunchKernelGGL(k_chain_recentre, dim3(b.maxseg, b.A), dim3(kScanThreads), 0, s, b);
         hipLaunchKernelGGL(k_chain_tables<true>, tgrid, dim3(kThreads), 0, s, b, 1);
+        hipLaunchKernelGGL(k_chain_compose, cgrid, dim3(kThreads), 0, s, b, 1);
         hipLaunchKernelGGL(k_chain_stitch, dim3(b.maxseg, b.A), dim3(kScanThreads), lds, s, b, 1, (seq << 16) | (unsigned)(rep + 1));
     }
     if (!clean) hipLaunchKernelGGL(k_chain_fallback, dim3(b.maxseg, b.A), dim3(64), 0, s, b);
