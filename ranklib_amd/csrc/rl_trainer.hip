@@ -981,7 +981,8 @@ static int enqueue_round(rl_trainer *t)
     }
     // the last block of k_hist_finish runs the growth bookkeeping (select_step); node records live in LDS when they fit
     const int nodes_in_lds = (select_lds_bytes(c.L, c.NC, true, c.F, c.fs_on != 0) <= 60 * 1024) ? 1 : 0;
-    const size_t fin_lds = std::max((size_t)c.TS * (c.java ? 28 : 20) + 8, select_lds_bytes(c.L, c.NC, nodes_in_lds != 0, c.F, c.fs_on != 0));
+    const size_t par_lds = (c.TS <= kParCacheTS) ? (size_t)c.TS * 20 + 8 : 0;       // the parent's entries next to the bins (hist_finish_body)
+    const size_t fin_lds = std::max((size_t)c.TS * (c.java ? 28 : 20) + 8 + par_lds, select_lds_bytes(c.L, c.NC, nodes_in_lds != 0, c.F, c.fs_on != 0));      // bins + the parent's entries (hist_finish_body)
     const int jbg = (c.TS + 63) / 64;        // RL_FLAG_JAVA_ORDER: 64-bin groups of k_jhist (+ 1 block for the node totals)
     if (fin_lds > 128 * 1024) return fail(RL_ERR_UNSUPPORTED, "too many features / leaves for the growth bookkeeping in LDS (feature sampling needs 64 bytes per feature)");
     if (t->dist) {
@@ -1133,7 +1134,7 @@ static int enqueue_round(rl_trainer *t)
             else hipLaunchKernelGGL(k_jhist, dim3(c.n_live, jbg + 2, kSpec), dim3(64), 0, s, c, 0, jbg);
             hipLaunchKernelGGL((k_hist_finish<false, false, true>), dim3(c.n_live, kSpec), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
         } else if (t->fin_split || !nodes_in_lds) {       // (wide data; or node records that do not fit the LDS: the fused kernel has no path for them)
-            hipLaunchKernelGGL(k_hist_finish_wide, dim3(c.n_live, kSpec), dim3(kFinWideThreads), (size_t)c.TS * 20 + 8, s, c);
+            hipLaunchKernelGGL(k_hist_finish_wide, dim3(c.n_live, kSpec), dim3(kFinWideThreads), (size_t)c.TS * 20 + 8 + par_lds, s, c);
             hipLaunchKernelGGL(k_select, dim3(1), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
         } else hipLaunchKernelGGL((k_hist_finish<false, false>), dim3(c.n_live, kSpec), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
     }
