@@ -513,7 +513,10 @@ def main():
                 "ms_per_round": node["ms_per_round"], "docs_accumulated_per_round": node["docs_per_round"], "algorithmic_bytes_per_round": nb,
                 "frac_of_measured_gather32": (ach / gather_gbs) if gather_gbs else None,
                 "lds_atomics_per_cu_clock": node_atoms_clk,
-                "lds_atomics_frac_of_measured_peak": (node_atoms_clk / lds_cal["random_bins_plus_count"]) if (node_atoms_clk and lds_cal) else None,
+                # the calibration counts atomic GROUPS (here: a 64-bit sum + a 32-bit count = one pair) per CU and clock, so the fraction is pairs over
+                # pairs.  (Rounds 3-4 divided atomics -- two per pair -- by the pair rate and reported twice this fraction: 0.74 where 0.37 was meant.)
+                "lds_atomic_pairs_per_cu_clock": (node_atoms_clk / 2.0) if node_atoms_clk else None,
+                "lds_atomics_frac_of_measured_peak": (node_atoms_clk / 2.0 / lds_cal["random_bins_plus_count"]) if (node_atoms_clk and lds_cal) else None,
                 "traffic_source": ("live: bench.py re-ran itself under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel trace only); bytes = "
                                    "%.1f x FETCH_SIZE + WRITE_SIZE (factors: profiles/r02_fetch_calibration.txt)" % FETCH_FACTOR_GATHER32) if pmc else None,
                 "note": "algorithmic bytes (SURVEY.md 8d) = documents of the accumulated (smaller) children x (F*2 B bin ids + 8 B lambda + 4 B sample id); HIP events around "

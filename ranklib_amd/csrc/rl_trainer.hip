@@ -443,7 +443,7 @@ static int launch_rank(rl_trainer *t, DataSet &d, const double *scores, double *
 }
 
 template <bool ROOT>
-static void launch_hist(const Ctx &c, int gx, int gy, size_t lds, hipStream_t s)
+static void launch_hist(const Ctx &c, int gx, int gy, size_t lds, hipStream_t s, bool fq = false)
 {
     // the XCD-aware block map of k_hist wants a multiple of 8 chunks (the extra blocks exit); child passes: a bounded grid whose blocks walk the
     // step's chunks (k_hist), about one resident set of blocks (3 per CU)
@@ -469,6 +469,13 @@ static void launch_hist(const Ctx &c, int gx, int gy, size_t lds, hipStream_t s)
         if (c.hist_nt >= 1024) hipLaunchKernelGGL((k_hist<false, 16, kHistLdsStride, false, false, 1024>), g, dim3(1024), lds, s, c);
         else hipLaunchKernelGGL((k_hist<false, 16, kHistLdsStride, false, false, 512>), g, dim3(512), lds, s, c);
         return;
+    }
+    if constexpr (ROOT) {
+        if (fq && c.sub == 16 && c.TS <= kHistLdsStride && !c.any_runs) {      // root pass that quantises the lambdas itself (root_quant_fused)
+            if (c.p8) hipLaunchKernelGGL((k_hist<true, 16, kHistLdsStride, false, true, kThreads, false, true>), g, b, lds, s, c);
+            else hipLaunchKernelGGL((k_hist<true, 16, kHistLdsStride, false, false, kThreads, false, true>), g, b, lds, s, c);
+            return;
+        }
     }
     if (c.sub == 16 && c.TS <= kHistLdsStride) {
         // packed rows for the root pass only (measured at c2: 43 % fewer bytes buy the root pass 9 % -- it is bound by LDS atomics, not by HBM --
@@ -959,7 +966,11 @@ static int enqueue_round(rl_trainer *t)
     }
     hipLaunchKernelGGL(k_max_reduce, dim3(1), dim3(1024), 0, s, (const double *)t->d_wmax, n_max, &c.st->maxabs_bits);
     if (t->dist) { int rcd = t->dist->allreduce(&c.st->maxabs_bits, 1, DT_U64, OP_MAX, s); if (rcd) return rcd; }
-    hipLaunchKernelGGL(k_quantize, dim3(std::min(2048, (c.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, c);
+    // The plain one-GPU root pass makes the fixed-point lambdas itself (k_hist<.., FQ>): one pass over the documents and one launch less a round.
+    // Sharded, strict-order and sparse-column runs (their kernels between here and the root pass read q) and a regrown tree (q exists) keep k_quantize.
+    static const bool fq_env = !(getenv("RLHIP_FUSED_QUANT") && atoi(getenv("RLHIP_FUSED_QUANT")) == 0);
+    bool root_quant_fused = fq_env && !t->dist && !c.java && !c.sp_on && c.sub == 16 && c.TS <= kHistLdsStride && !c.any_runs;
+    if (!root_quant_fused) hipLaunchKernelGGL(k_quantize, dim3(std::min(2048, (c.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, c);
     const size_t hist_lds = (size_t)c.sub * ((c.sub == 16 && c.TS <= kHistLdsStride) ? kHistLdsStride : c.TS) * 12;    // int64 sums + int32 counts
     const int hist_gx = c.numFG * (kHistFG / c.sub);
     const size_t red_lds = (size_t)c.TS * 20;
@@ -974,7 +985,8 @@ static int enqueue_round(rl_trainer *t)
         const double root_bytes = c.sp_on ? (double)c.N * ((double)(c.numFG - c.sp_ngroups) * kHistFG * 2.0 + 8.0) + (double)t->sp_entries * 4.0
                                           : (double)c.N * ((double)c.F * 2.0 + 8.0);
         ScopedTiming tm(t, RL_KERNEL_HIST_ROOT, root_bytes);
-        launch_hist<true>(c, hist_gx, rootChunks, hist_lds, s);
+        launch_hist<true>(c, hist_gx, rootChunks, hist_lds, s, root_quant_fused);
+        root_quant_fused = false;        // (a regrown tree reads the q / r this pass has stored)
         if (c.sp_on) {
             hipLaunchKernelGGL(k_hist_sp<kHistLdsStride>, dim3(c.sp_ngroups, rootChunks), dim3(kSpThreads), (size_t)kHistFG * kHistLdsStride * 8, s, c, rootCs);
         }
@@ -1228,7 +1240,7 @@ static int enqueue_round(rl_trainer *t)
         if (rcs) return rcs;
         if (other_cut && (c.tie_on & 2)) { c.tie_on = 1; t->tie_regrown++; goto regrow; }
     }
-    hipLaunchKernelGGL(k_score_update, dim3(std::min(4096, (c.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, c);
+    hipLaunchKernelGGL(k_score_update, dim3(std::max(1, std::min(4096, (c.N + kScoreBatch * kThreads - 1) / (kScoreBatch * kThreads)))), dim3(kThreads), 0, s, c);
     hipLaunchKernelGGL(k_export_tree, dim3(1), dim3(kThreads), 0, s, c, t->ens, m);
     RL_HIP(hipGetLastError());
     // per-round training metric (LambdaMART.java:216)
