@@ -355,9 +355,14 @@ static bool spin_until(const unsigned long long *word, Pred ok, unsigned long lo
     }
 }
 
-static void enqueue_chain(rl_trainer *t, const ChainBufs &b, const ChainSource &src, hipStream_t s = nullptr)
+static void enqueue_chain(rl_trainer *t, const ChainBufs &b_in, const ChainSource &src, hipStream_t s = nullptr)
 {
     if (!s) s = t->stream;
+    // The device cuts its repair passes into windows (kChainWinMax chunks) only when the host watches them and keeps repairing (the progress word);
+    // a host that enqueues its passes blindly (no pinned word, RLHIP_STEP_AHEAD=0) gets passes that rebuild everything that remains -- otherwise a
+    // chain longer than kChainRepairs windows ended in the serial fallback (exact, but ~100 ms for a 40 M-document leaf).
+    ChainBufs b = b_in;
+    if (!(b.h_progress != nullptr && t->step_ahead > 0)) { b.progress = nullptr; b.h_progress = nullptr; }
     const unsigned tb = (unsigned)((b.cap_tiles + 3) / 4);
     hipLaunchKernelGGL(k_chain_prefix, dim3(tb), dim3(kThreads), 0, s, b, src);
     hipLaunchKernelGGL(k_chain_scan_tiles, dim3(b.A), dim3(kScanThreads), 0, s, b);
