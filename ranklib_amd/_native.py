@@ -303,7 +303,8 @@ class Trainer:
 
     def dist_init_callback(self, rank, n_ranks, allreduce, allgather, alltoallv=None):
         """host transport: allreduce(np_array, op) reduces in place, allgather(np_uint8_in) -> np_uint8 [n_ranks*len],
-        alltoallv(list of n_ranks np_uint8 arrays to send) -> list of n_ranks np_uint8 arrays received (None: emulated with all-gathers)"""
+        alltoallv(list of n_ranks np_uint8 arrays to send, list of n_ranks byte counts to receive) -> list of n_ranks np_uint8 arrays received
+        (None: emulated with all-gathers)"""
         def _ar(user, ptr, count, dtype, op):
             try:
                 arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), (count * np.dtype(DT_NUMPY[dtype]).itemsize,)).view(DT_NUMPY[dtype])

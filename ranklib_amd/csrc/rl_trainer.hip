@@ -1472,8 +1472,8 @@ int rl_create(const rl_params *p, rl_trainer **out)
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist_finish<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    RL_HIP(hipFuncSetAttribute((const void *)k_rank_block, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaBlockCap * kRankLdsPerDoc));
-    RL_HIP(hipFuncSetAttribute((const void *)k_rank_mixed, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(kLambdaBlockCap, (kRankBlockThreads / 64) * kLambdaWaveCap) * kRankLdsPerDoc));
+    RL_HIP(hipFuncSetAttribute((const void *)k_rank_block, hipFuncAttributeMaxDynamicSharedMemorySize, ((kLambdaBlockCap + 63) & ~63) * kRankLdsPerDoc));      // (max_big is rounded up to 64 documents)
+    RL_HIP(hipFuncSetAttribute((const void *)k_rank_mixed, hipFuncAttributeMaxDynamicSharedMemorySize, std::max((kLambdaBlockCap + 63) & ~63, (kRankBlockThreads / 64) * kLambdaWaveCap) * kRankLdsPerDoc));
     RL_HIP(hipFuncSetAttribute((const void *)k_lambda_tiny, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaTinyGroups * lambda_tiny_group_bytes(kLambdaFusedMaxK)));
     RL_HIP(hipFuncSetAttribute((const void *)k_lambda_fused<256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaFusedMaxK * (256 + 8) * 16 + 2048));
     RL_HIP(hipFuncSetAttribute((const void *)k_lambda_fused<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaFusedMaxK * (256 + 8) * 16 + 8192));
