@@ -77,6 +77,7 @@ struct SlotRec {
     int32_t tile0, ntiles;                   // partition tiles [tile0, tile0+ntiles) of this step's grid
     int32_t chunk0, nchunks;                 // histogram chunks [chunk0, chunk0+nchunks) (upper bound) of this step's grid
     int32_t nleft;                           // local size of the left child when known in advance (one GPU), else -1
+    int32_t cs, cs_pad;                      // documents per histogram chunk of the built child when the step's chunks were balanced (balance_slots), 0 = chunk_docs' rule
     long long sq_left;                       // fixed-point sum of lambda^2 over the BUILT child (k_part_scatter; the sibling's is parent - built)
 };
 
@@ -141,6 +142,7 @@ struct Ctx {
     int32_t sub;            // features of a group handled per histogram block (kHistFG unless the threshold table is huge)
     const int32_t *mode;    // [F] most populated bin of every feature: never accumulated, rebuilt as total - others
     const uint32_t *runs;   // [numFG] bit j: feature 16 g + j comes in runs of equal bins (query-level columns): quad-folded atomics in k_hist<.., RUNS>
+    int32_t balance, balance_cap, balance_target, balance_min;        // balance_slots (RLHIP_BALANCE=0: chunk_docs' per-node rule always)
     int32_t any_runs;       // some column does: the RUNS instantiation of k_hist is launched
     const float *thr;       // [F][TS]
     const int32_t *nthr;    // [F]

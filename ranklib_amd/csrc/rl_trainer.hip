@@ -453,7 +453,9 @@ static void launch_hist(const Ctx &c, int gx, int gy, size_t lds, hipStream_t s,
     // the XCD-aware block map of k_hist wants a multiple of 8 chunks (the extra blocks exit); child passes: a bounded grid whose blocks walk the
     // step's chunks (k_hist), about one resident set of blocks (3 per CU)
     static const int grid_blocks = getenv("RLHIP_HIST_GRID") ? atoi(getenv("RLHIP_HIST_GRID")) : 1024;
-    const auto bounded = [&](int gxx) { return ROOT ? ((gy + 7) & ~7) : std::min((gy + 7) & ~7, std::max(8, ((grid_blocks + gxx - 1) / gxx + 7) & ~7)); };
+    // (balanced steps -- balance_slots -- want exactly balance_target rows: block row r then works through the chunks r, r + balance_target, ..)
+    const auto bounded = [&](int gxx) { return ROOT ? ((gy + 7) & ~7) : (c.balance && c.n_ranks == 1 && !getenv("RLHIP_HIST_GRID")) ? std::min((gy + 7) & ~7, c.balance_target)
+                                                                      : std::min((gy + 7) & ~7, std::max(8, ((grid_blocks + gxx - 1) / gxx + 7) & ~7)); };
     const dim3 g(gx, bounded(gx)), b(kThreads);
     if (!ROOT && c.crows && c.sub == 16 && c.TS <= kHistLdsStride && !c.any_runs) {      // sparse data: compact rows (k_compact_rows)
         hipLaunchKernelGGL((k_hist<false, 16, kHistLdsStride, false, false, kThreads, true>), g, b, lds, s, c);
@@ -1610,6 +1612,14 @@ int rl_init(rl_trainer *t)
     // c3, 700 columns: -1.8 %: every chunk more is another partial histogram of F x T x 12 bytes)
     c.node_chunk = (N <= (2 << 20) && F <= 256) ? 4096 : kNodeChunk;
     if (const char *e = getenv("RLHIP_NODE_CHUNK")) c.node_chunk = std::min(kNodeChunk, std::max(1024, atoi(e) & ~255));
+    // balanced chunks for the steps that fill the chip (balance_slots): rows of the child-pass grid = chunks per round of blocks, largest chunk, steps of at most balance_min chunks keep chunk_docs' rule
+    // (measured, same box, rounds/s: c2 362.6 -> 366.2 and 316.5 -> 319.9 over 300 rounds, c2ns 346.5 -> 349.8, c1 633.9 -> 638.5; c3, 700 columns = 44 feature groups per chunk:
+    // 500 -> 498: wide data keeps the per-node rule)
+    c.balance = (F <= 256) ? 1 : 0; c.balance_cap = kChunk; c.balance_target = 80; c.balance_min = 40;
+    if (const char *e = getenv("RLHIP_BALANCE")) c.balance = atoi(e) != 0;
+    if (const char *e = getenv("RLHIP_BALANCE_CAP")) c.balance_cap = std::min(kChunk, std::max(1024, atoi(e) & ~255));
+    if (const char *e = getenv("RLHIP_BALANCE_TARGET")) c.balance_target = std::max(8, atoi(e) & ~7);
+    if (const char *e = getenv("RLHIP_BALANCE_MIN")) c.balance_min = std::max(1, atoi(e));
     c.metric = t->p.metric; c.mart = (t->p.ranker == RL_RANKER_MART) ? 1 : 0;
     // lazy Java-order tie-break (rl_tie.inc): the default path's exact ties resolved as the Java's summation order resolves them.  Not with
     // feature sampling (the Java's draw is unseeded: nothing to match), not sharded (the Java's order is ONE sequence over all documents), not in
