@@ -456,6 +456,9 @@ static void launch_hist(const Ctx &c, int gx, int gy, size_t lds, hipStream_t s,
     // (balanced steps -- balance_slots -- want exactly balance_target rows: block row r then works through the chunks r, r + balance_target, ..)
     const auto bounded = [&](int gxx) { return ROOT ? ((gy + 7) & ~7) : (c.balance && c.n_ranks == 1 && !getenv("RLHIP_HIST_GRID")) ? std::min((gy + 7) & ~7, c.balance_target)
                                                                       : std::min((gy + 7) & ~7, std::max(8, ((grid_blocks + gxx - 1) / gxx + 7) & ~7)); };
+    // (RLHIP_HIST_LDSPAD: extra dynamic LDS per child-pass block -- 28 KB caps a CU at two blocks; a measuring aid)
+    static const size_t lds_pad = getenv("RLHIP_HIST_LDSPAD") ? (size_t)atoi(getenv("RLHIP_HIST_LDSPAD")) : 0;
+    if (!ROOT) lds += lds_pad;
     const dim3 g(gx, bounded(gx)), b(kThreads);
     if (!ROOT && c.crows && c.sub == 16 && c.TS <= kHistLdsStride && !c.any_runs) {      // sparse data: compact rows (k_compact_rows)
         hipLaunchKernelGGL((k_hist<false, 16, kHistLdsStride, false, false, kThreads, true>), g, b, lds, s, c);
@@ -1613,9 +1616,9 @@ int rl_init(rl_trainer *t)
     c.node_chunk = (N <= (2 << 20) && F <= 256) ? 4096 : kNodeChunk;
     if (const char *e = getenv("RLHIP_NODE_CHUNK")) c.node_chunk = std::min(kNodeChunk, std::max(1024, atoi(e) & ~255));
     // balanced chunks for the steps that fill the chip (balance_slots): rows of the child-pass grid = chunks per round of blocks, largest chunk, steps of at most balance_min chunks keep chunk_docs' rule
-    // (measured, same box, rounds/s: c2 362.6 -> 366.2 and 316.5 -> 319.9 over 300 rounds, c2ns 346.5 -> 349.8, c1 633.9 -> 638.5; c3, 700 columns = 44 feature groups per chunk:
-    // 500 -> 498: wide data keeps the per-node rule)
-    c.balance = (F <= 256) ? 1 : 0; c.balance_cap = kChunk; c.balance_target = 80; c.balance_min = 40;
+    // (measured, same box, rounds/s, 56 rows: c2 362.6 -> 372.7 and 316.5 -> 326.0 over 300 rounds, c2ns 346.5 -> 363.9, c1 632 -> 646; c3, 700 columns = 44 feature groups per
+    // chunk: 500 -> 498 at 80 rows: wide data keeps the per-node rule)
+    c.balance = (F <= 256) ? 1 : 0; c.balance_cap = kChunk; c.balance_target = 56; c.balance_min = 28;
     if (const char *e = getenv("RLHIP_BALANCE")) c.balance = atoi(e) != 0;
     if (const char *e = getenv("RLHIP_BALANCE_CAP")) c.balance_cap = std::min(kChunk, std::max(1024, atoi(e) & ~255));
     if (const char *e = getenv("RLHIP_BALANCE_TARGET")) c.balance_target = std::max(8, atoi(e) & ~7);
