@@ -1616,9 +1616,15 @@ int rl_init(rl_trainer *t)
     c.node_chunk = (N <= (2 << 20) && F <= 256) ? 4096 : kNodeChunk;
     if (const char *e = getenv("RLHIP_NODE_CHUNK")) c.node_chunk = std::min(kNodeChunk, std::max(1024, atoi(e) & ~255));
     // balanced chunks for the steps that fill the chip (balance_slots): rows of the child-pass grid = chunks per round of blocks, largest chunk, steps of at most balance_min chunks keep chunk_docs' rule
-    // (measured, same box, rounds/s, 56 rows: c2 362.6 -> 372.7 and 316.5 -> 326.0 over 300 rounds, c2ns 346.5 -> 363.9, c1 632 -> 646; c3, 700 columns = 44 feature groups per
-    // chunk: 500 -> 498 at 80 rows: wide data keeps the per-node rule)
-    c.balance = (F <= 256) ? 1 : 0; c.balance_cap = kChunk; c.balance_target = 56; c.balance_min = 28;
+    // Rows: about two blocks per CU -- 512 / (feature-group blocks per chunk), to the nearest multiple of 8 (k_hist's XCD map), at least 16.
+    // Measured, same box, rounds/s: c2 / c1 (9 groups, 56 rows) 362.6 -> 372.7, 316.5 -> 326.0 over 300 rounds, c2ns 346.5 -> 363.9, c1 632 -> 646 (80 rows: +1 %, 64 / 72: worse
+    // than none, 48: +0.5 %); c3 (44 groups) 486 -> 522 with 16 rows (8 rows: 477, 24 rows: 494).
+    {
+        const int gxb = (F + kHistFG - 1) / kHistFG;
+        c.balance = 1; c.balance_cap = kChunk;
+        c.balance_target = std::max(16, ((512 / std::max(gxb, 1) + 4) / 8) * 8);
+        c.balance_min = c.balance_target / 2;
+    }
     if (const char *e = getenv("RLHIP_BALANCE")) c.balance = atoi(e) != 0;
     if (const char *e = getenv("RLHIP_BALANCE_CAP")) c.balance_cap = std::min(kChunk, std::max(1024, atoi(e) & ~255));
     if (const char *e = getenv("RLHIP_BALANCE_TARGET")) c.balance_target = std::max(8, atoi(e) & ~7);
