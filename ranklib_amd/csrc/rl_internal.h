@@ -77,7 +77,8 @@ struct SlotRec {
     int32_t tile0, ntiles;                   // partition tiles [tile0, tile0+ntiles) of this step's grid
     int32_t chunk0, nchunks;                 // histogram chunks [chunk0, chunk0+nchunks) (upper bound) of this step's grid
     int32_t nleft;                           // local size of the left child when known in advance (one GPU), else -1
-    int32_t cs, cs_pad;                      // documents per histogram chunk of the built child when the step's chunks were balanced (balance_slots), 0 = chunk_docs' rule
+    int32_t cs, skip_hist;                   // cs: documents per histogram chunk of the built child when the step's chunks were balanced (balance_slots), 0 = chunk_docs' rule;
+                                             // skip_hist: the split that fills the leaf budget (k_select2) -- partitioned, no child histogram is accumulated or finished
     long long sq_left;                       // fixed-point sum of lambda^2 over the BUILT child (k_part_scatter; the sibling's is parent - built)
 };
 
@@ -144,6 +145,7 @@ struct Ctx {
     const uint32_t *runs;   // [numFG] bit j: feature 16 g + j comes in runs of equal bins (query-level columns): quad-folded atomics in k_hist<.., RUNS>
     int32_t balance, balance_cap, balance_target, balance_min;        // balance_slots (RLHIP_BALANCE=0: chunk_docs' per-node rule always)
     int32_t any_runs;       // some column does: the RUNS instantiation of k_hist is launched
+    int32_t skip_last;      // k_select2: the step of the split that fills the leaf budget skips its child histograms (RLHIP_SKIP_LAST=0: off)
     const float *thr;       // [F][TS]
     const int32_t *nthr;    // [F]
     const int32_t *feature_ids;
@@ -173,6 +175,7 @@ struct Ctx {
     int32_t *tile_cnt;                                                 // [nTiles]
     long long *tile_sq;                                                // [nTiles] lambda^2 partial of each partition tile's left members
     int32_t *leaf_node, *leaf_start;                                   // [MAXN], [MAXN+1]
+    uint16_t *leaf_of;                                                 // [N] leaf (position in the leaf table) of every document, written with the leaf sums' gather (k_chain_prefix): k_score_stream
     int32_t *grow_stats;                                               // [4] cumulative: growth steps, nodes prepared, splits committed, trees
     unsigned long long *grow_docs;                                     // [4] cumulative documents: accumulated into child histograms (the smaller child of every
                                                                        // PREPARED node), partitioned (prepared nodes), left children of COMMITTED splits (what the

@@ -17,9 +17,11 @@
 
 #include "rl_internal.h"
 #include "rl_device.h"
+#include "rl_wave.h"
 #include "rl_kernels_init.inc"
 #include "rl_chain.inc"
 #include "rl_kernels_round.inc"
+#include "rl_step2.inc"
 #include "rl_java_order.inc"
 #include "rl_csc.inc"
 #include "rl_tie.inc"
@@ -106,6 +108,7 @@ struct rl_trainer {
     long long tie_stalls = 0, tie_nodes = 0, tie_chain_nodes = 0, tie_chain_docs = 0;      // lazy tie-break (rl_tie.inc): resolutions run, nodes resolved, chain nodes / documents summed
     long long tie_batches = 0;      // of the resolutions, the batched ones at the end of a tree (deferred ties)
     bool fin_split = false;      // wide data: k_hist_finish_wide + k_select instead of the fused finish (rl_init)
+    bool step2 = true;           // k_fin2 (+ k_select2) instead of the fused finish / bookkeeping kernel (rl_step2.inc; RLHIP_STEP2=0: the round-4 kernels)
     long long tie_phase_us[6] = {0, 0, 0, 0, 0, 0};   // RLHIP_TIE_PROF: host microseconds per phase of resolve_ties (printed by rl_destroy)
     long long tie_regrown = 0;      // trees grown a second time because a deferred tie over several features hid two different cuts (k_tie_verify)
     long long tie_us = 0, tie_spec_segs = 0, tie_spec_miss = 0, tie_spec_serial = 0, tie_spec_repairs = 0;      // host time in resolve_ties; segments evaluated, window misses, serial segments, repair passes
@@ -1017,6 +1020,9 @@ static int enqueue_round(rl_trainer *t)
         if (c.jmap) hipLaunchKernelGGL(k_jhist2, dim3(c.n_live + 1, 1), dim3(kJ2Threads), 0, s, c, 1, c.jmap, c.jinv, c.jone);
         else hipLaunchKernelGGL(k_jhist, dim3(c.n_live, jbg + 2, 1), dim3(64), 0, s, c, 1, jbg);
         hipLaunchKernelGGL((k_hist_finish<true, false, true>), dim3(c.n_live), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
+    } else if (t->step2 && c.TS <= kFin2MaxT) {       // rl_step2.inc
+        hipLaunchKernelGGL(k_fin2_root, dim3(c.n_live), dim3(kFin2RootThreads), 0, s, c, rootChunks);
+        hipLaunchKernelGGL(k_select_root, dim3(1), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
     } else hipLaunchKernelGGL((k_hist_finish<true, false>), dim3(c.n_live), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
     // Growth steps: each prepares up to kSpec queue nodes and commits as many splits as the fit loop allows; L-1 steps
     // always suffice (every step commits at least the head of the queue); finished trees make the rest no-ops.
@@ -1155,6 +1161,13 @@ static int enqueue_round(rl_trainer *t)
             if (c.jmap) hipLaunchKernelGGL(k_jhist2, dim3(c.n_live + 1, kSpec), dim3(kJ2Threads), 0, s, c, 0, c.jmap, c.jinv, c.jone);
             else hipLaunchKernelGGL(k_jhist, dim3(c.n_live, jbg + 2, kSpec), dim3(64), 0, s, c, 0, jbg);
             hipLaunchKernelGGL((k_hist_finish<false, false, true>), dim3(c.n_live, kSpec), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
+        } else if (t->step2 && c.TS <= kFin2MaxT) {
+            // rl_step2.inc: one bin per thread, DPP scans, plain stores -- then the bookkeeping as a launch of its own
+            hipLaunchKernelGGL(k_fin2, dim3(c.n_live, kSpec), dim3(kFin2Threads), 0, s, c);
+            const size_t sel2_lds = select2_lds_bytes(c.L, c.NC);
+            if (!c.fs_on && c.F <= kSel2MaxF && c.L > 0 && c.L + 2 <= 64 && sel2_lds <= 60 * 1024)
+                hipLaunchKernelGGL(k_select2, dim3(1), dim3(kSel2Threads), sel2_lds, s, c);
+            else hipLaunchKernelGGL(k_select, dim3(1), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
         } else if (t->fin_split || !nodes_in_lds) {       // (wide data; or node records that do not fit the LDS: the fused kernel has no path for them)
             hipLaunchKernelGGL(k_hist_finish_wide, dim3(c.n_live, kSpec), dim3(kFinWideThreads), (size_t)c.TS * 20 + 8 + par_lds, s, c);
             hipLaunchKernelGGL(k_select, dim3(1), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
@@ -1173,6 +1186,9 @@ static int enqueue_round(rl_trainer *t)
             if (!ended) goto grow;
         } else defer_seen = sth.defer_any != 0;
     }
+    // the score update streams over the documents when the leaf sums' gather can leave every document's leaf behind (one GPU, parallel chains, <= 1024 leaves)
+    static const bool stream_env = !(getenv("RLHIP_SCORE_STREAM") && atoi(getenv("RLHIP_SCORE_STREAM")) == 0);
+    const bool stream_scores = stream_env && !t->dist && !(t->p.flags & RL_FLAG_SERIAL_CHAIN) && c.leaf_of != nullptr && c.L > 0 && c.L <= 1024;
     hipLaunchKernelGGL(k_leaf_table, dim3(1), dim3(kThreads), 0, s, c, t->leaf_chain, t->d_seg_buf);
     if (t->p.flags & RL_FLAG_SERIAL_CHAIN) {
         hipLaunchKernelGGL(k_leaf_chain, dim3(c.L), dim3(64), 0, s, c);
@@ -1237,7 +1253,7 @@ static int enqueue_round(rl_trainer *t)
         }
         hipLaunchKernelGGL(k_leaf_output, dim3((c.L + kThreads - 1) / kThreads), dim3(kThreads), 0, s, c, t->gchain);
     } else {   // K7: the two Java float running sums of every leaf, exactly, in parallel (rl_chain.inc)
-        ChainSource src{nullptr, nullptr, c.lw, c.idx[0], c.idx[1], t->d_seg_buf};
+        ChainSource src{nullptr, nullptr, c.lw, c.idx[0], c.idx[1], t->d_seg_buf, stream_scores ? c.leaf_of : nullptr};
         enqueue_chain(t, t->leaf_chain, src);
         hipLaunchKernelGGL(k_leaf_output, dim3((c.L + kThreads - 1) / kThreads), dim3(kThreads), 0, s, c, t->leaf_chain);
     }
@@ -1250,7 +1266,8 @@ static int enqueue_round(rl_trainer *t)
         if (rcs) return rcs;
         if (other_cut && (c.tie_on & 2)) { c.tie_on = 1; t->tie_regrown++; goto regrow; }
     }
-    hipLaunchKernelGGL(k_score_update, dim3(std::max(1, std::min(4096, (c.N + kScoreBatch * kThreads - 1) / (kScoreBatch * kThreads)))), dim3(kThreads), 0, s, c);
+    if (stream_scores) hipLaunchKernelGGL(k_score_stream, dim3(std::max(1, std::min(2048, (c.N + kScoreBatch * kThreads - 1) / (kScoreBatch * kThreads)))), dim3(kThreads), 0, s, c);
+    else hipLaunchKernelGGL(k_score_update, dim3(std::max(1, std::min(4096, (c.N + kScoreBatch * kThreads - 1) / (kScoreBatch * kThreads)))), dim3(kThreads), 0, s, c);
     hipLaunchKernelGGL(k_export_tree, dim3(1), dim3(kThreads), 0, s, c, t->ens, m);
     RL_HIP(hipGetLastError());
     // per-round training metric (LambdaMART.java:216)
@@ -1626,6 +1643,9 @@ int rl_init(rl_trainer *t)
         c.balance_min = c.balance_target / 2;
     }
     if (const char *e = getenv("RLHIP_BALANCE")) c.balance = atoi(e) != 0;
+    c.skip_last = 1;
+    if (const char *e = getenv("RLHIP_SKIP_LAST")) c.skip_last = atoi(e) != 0;
+    t->step2 = !(getenv("RLHIP_STEP2") && atoi(getenv("RLHIP_STEP2")) == 0);
     if (const char *e = getenv("RLHIP_BALANCE_CAP")) c.balance_cap = std::min(kChunk, std::max(1024, atoi(e) & ~255));
     if (const char *e = getenv("RLHIP_BALANCE_TARGET")) c.balance_target = std::max(8, atoi(e) & ~7);
     if (const char *e = getenv("RLHIP_BALANCE_MIN")) c.balance_min = std::max(1, atoi(e));
@@ -2155,6 +2175,7 @@ int rl_init(rl_trainer *t)
         RL_HIP(t->pool.alloc(&c.trace, (size_t)64 * 3 * kTraceBlocks * kTraceStamps)); RL_HIP(hipMemset(c.trace, 0, (size_t)64 * 3 * kTraceBlocks * kTraceStamps * sizeof(long long)));
     }
     RL_HIP(t->pool.alloc(&c.leaf_node, (size_t)c.MAXN + 1)); RL_HIP(t->pool.alloc(&c.leaf_start, (size_t)c.MAXN + 2));
+    RL_HIP(t->pool.alloc(&c.leaf_of, (size_t)c.Npad + 64));
     RL_HIP(t->pool.alloc(&c.round_metric, (size_t)2 * t->p.n_trees));
     RL_HIP(hipMemset(c.round_metric, 0, (size_t)2 * t->p.n_trees * sizeof(float)));
     RL_HIP(hipMemset(c.lw, 0, N * sizeof(double2)));

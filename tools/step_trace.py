@@ -52,6 +52,12 @@ for s in range(64):
     if prev_end is not None:
         rows.append([gap_p, p1 - p0, h0 - p1, h1 - h0, f0 - h1, f1 - f0, end - f1, total])
     prev_end = end
+sel2 = [(s_, clk[s_][20:26] - clk[s_][20]) for s_ in range(64) if clk[s_][25] > clk[s_][20] > 0]
+if sel2:       # k_select2 (rl_step2.inc): stamps of its phases since the kernel's first instruction
+    print("bookkeeping kernel (k_select2), microseconds since its entry: loads landed, A best feature, B children, C fit loop, D next slots")
+    for s_, r in sel2:
+        print("%4d " % s_ + " ".join("%7.2f" % v for v in r[1:]))
+    print("mean " + " ".join("%7.2f" % v for v in np.mean(np.array([r for _, r in sel2]), axis=0)[1:]))
 if rows:
     m = np.mean(np.array(rows), axis=0)
     print("mean over %d steps: part gap %.1f span %.1f | hist gap %.1f span %.1f | finish gap %.1f span %.1f | select tail %.1f | step %.1f" % ((len(rows),) + tuple(m)))
