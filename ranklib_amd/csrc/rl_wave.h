@@ -61,6 +61,15 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return readlane_u
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) { return readlane_u64(wave_scan_u64(v), 63); }
 __device__ __forceinline__ i128 wave_sum_i128(i128 v) { return readlane_i128(wave_scan_i128(v), 63); }
 
+// maximum over the 64 lanes, uniform (identity 0)
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v)
+{
+#define RL_MX(CTRL, RM) { const uint64_t o_ = dpp_u64<CTRL, RM>(v); v = o_ > v ? o_ : v; }
+    RL_MX(kDppShr1, 0xf) RL_MX(kDppShr2, 0xf) RL_MX(kDppShr4, 0xf) RL_MX(kDppShr8, 0xf) RL_MX(kDppBcast15, 0xa) RL_MX(kDppBcast31, 0xc)
+#undef RL_MX
+    return readlane_u64(v, 63);
+}
+
 // sums over the two 32-lane halves: lane 31 / lane 63 of the scan before the last step
 __device__ __forceinline__ uint32_t half_scan_u32(uint32_t v)
 {
