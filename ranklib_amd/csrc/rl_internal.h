@@ -24,6 +24,12 @@ constexpr int kMinChunk = 512;       // smallest chunk a (small) node is cut int
 #define RL_HIST_DOCS 2
 #endif
 constexpr int kHistDocs = RL_HIST_DOCS;         // samples per thread and iteration of the histogram kernel
+#ifndef RL_LOOKBACK2
+#define RL_LOOKBACK2 1
+#endif
+#ifndef RL_HIST_PREFETCH
+#define RL_HIST_PREFETCH 0
+#endif
 constexpr int kHistFG = 16;          // features per group of the histogram layout gbins[group][doc][kHistFG]
 #ifndef RL_PART_TILE
 #define RL_PART_TILE 2048
@@ -163,6 +169,7 @@ struct Ctx {
     long long *ql[2];        // fixed-point lambda in sample-list order, valid for the ranges of BUILT children only (written by the partition
                              // that creates them; the lists themselves carry document ids alone)
     unsigned long long *tile_desc;   // [nTiles] look-back descriptors of the single-pass partition
+    unsigned long long *tile_gdesc;  // [nTiles / 64 + kSpec + 1] totals of the groups of 64 tiles (lookback2_exclusive)
     NodeRec *nodes;
     TreeState *st;
     int32_t *queue;

@@ -1620,7 +1620,7 @@ int rl_init(rl_trainer *t)
     c.mls = t->p.min_leaf_support; c.lr = t->p.learning_rate;
     // chunks a child node is cut into: every chunk flushes a partial histogram of F x T x 12 bytes that the finish reads back, so wide data wants fewer
     // (measured, rounds/s: c3, 700 columns: 3 / 4 / 6 / 8 / 12 / 16 / 24 -> 542 / 548 / 548 / 549-556 / 534 / 537 / 513; c2, 136 columns: flat from 8 to 32)
-    c.node_div = std::max(4, std::min(12, (int)(12.0 * std::sqrt(136.0 / (double)std::max(F, 1)) + 0.5))); c.node_min = kMinChunk;
+    c.node_div = std::max(4, std::min(24, (int)(24.0 * 136.0 / (double)std::max(F, 1) + 0.5)));      // (round 5, k_fin2: 16 partials per thread in one batch -- c2 sustained 345 -> 351 from 12 to 24 chunks; wide data keeps few) c.node_min = kMinChunk;
     c.fs_size = F; c.fs_on = 0; c.seed = t->p.seed;
     if (t->p.feature_sampling_rate > 0.0f && t->p.feature_sampling_rate < 1.0f) { c.fs_size = (int32_t)(t->p.feature_sampling_rate * (float)F); c.fs_on = c.fs_size < F ? 1 : 0; }   // :274
     c.hist_nt = kThreads; c.sub_child = 16;
@@ -1785,7 +1785,7 @@ int rl_init(rl_trainer *t)
         RL_HIP(hipMemcpy(d_vcol, t->vcol.data(), (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice));
         c.vcol = d_vcol;
         c.F = F; if (!c.fs_on) c.fs_size = F;          // (with feature sampling fs_size stays a number of REAL features: the draw is over columns)
-        c.node_div = std::max(4, std::min(12, (int)(12.0 * std::sqrt(136.0 / (double)std::max(F, 1)) + 0.5)));
+        c.node_div = std::max(4, std::min(24, (int)(24.0 * 136.0 / (double)std::max(F, 1) + 0.5)));      // (round 5, k_fin2: 16 partials per thread in one batch -- c2 sustained 345 -> 351 from 12 to 24 chunks; wide data keeps few)
         if (const char *e = getenv("RLHIP_NODE_DIV")) c.node_div = std::max(1, atoi(e));
         // exact ties: the first candidate in the Java's scan order.  The lazy re-decision needs the Java's own f64 prefix over ALL bins of a real feature,
         // which a run of a split table does not hold (its first bin is a merged sum)
@@ -2162,6 +2162,7 @@ int rl_init(rl_trainer *t)
     RL_HIP(t->pool.alloc(&c.fb_root, (size_t)2 + kSpec)); c.fb_sq = c.fb_root + 2;
     RL_HIP(t->pool.alloc(&c.tile_cnt, (size_t)c.nTiles)); RL_HIP(t->pool.alloc(&c.tile_sq, (size_t)c.nTiles));
     RL_HIP(t->pool.alloc(&c.tile_desc, (size_t)c.nTiles)); RL_HIP(hipMemset(c.tile_desc, 0, (size_t)c.nTiles * 8));
+    RL_HIP(t->pool.alloc(&c.tile_gdesc, (size_t)c.nTiles / 64 + kSpec + 2)); RL_HIP(hipMemset(c.tile_gdesc, 0, ((size_t)c.nTiles / 64 + kSpec + 2) * 8));
     RL_HIP(t->pool.alloc(&c.grow_stats, (size_t)4)); RL_HIP(hipMemset(c.grow_stats, 0, 16));
     RL_HIP(t->pool.alloc(&c.grow_docs, (size_t)4)); RL_HIP(hipMemset(c.grow_docs, 0, 32));
     c.steplog = nullptr;
