@@ -511,7 +511,7 @@ def main():
                 "traffic_over_algorithmic": (node_traffic_round / nb) if node_traffic_round else None,
                 "algorithmic_bytes_per_launch": nb / L_round, "avg_launch_ms": launch_ms, "launches_per_round": L_round,
                 "ms_per_round": node["ms_per_round"], "docs_accumulated_per_round": node["docs_per_round"], "algorithmic_bytes_per_round": nb,
-                "frac_of_measured_gather32": (ach / gather_gbs) if gather_gbs else None,
+                "frac_of_measured_gather32": (ach / gather_gbs) if gather_gbs else None,      # of THIS LIBRARY's own 32-byte row-gather kernel (rl_debug_membench mode 3), not of a hardware figure
                 "lds_atomics_per_cu_clock": node_atoms_clk,
                 # the calibration counts atomic GROUPS (here: a 64-bit sum + a 32-bit count = one pair) per CU and clock, so the fraction is pairs over
                 # pairs.  (Rounds 3-4 divided atomics -- two per pair -- by the pair rate and reported twice this fraction: 0.74 where 0.37 was meant.)
@@ -528,6 +528,7 @@ def main():
             out["roofline"] = dict(root_entry)
         out["roofline"]["lds_atomic_calibration"] = lds_cal
         out["roofline"]["measured_copy_GBps"] = copy_gbs
+        out["roofline"]["guide_copy_GBps"] = 6290.0       # float4 copy measured in /opt/skills/guides/MI355X_MICROARCH.md: what the fractions "of measured copy" should be read against if this library's copy kernel falls short of it
         out["roofline"]["measured_read_GBps"] = read_gbs
         out["roofline"]["measured_gather32_GBps"] = gather_gbs
         out["roofline"]["round"] = round_entry
@@ -583,6 +584,34 @@ def main():
                                         "rounds_per_s": args.c1_trees / dt1, "seconds": dt1, "ndcg10_train": float(g1.round_metrics(args.c1_trees - 1)[0]),
                                         "tie_resolutions": int(ts1[0]), "tie_host_ms": float(ts1[4]) / 1e3}
         del g1
+        # ... and once more with a held-out set (a fifth of the shape's size, rl_set_validation, early stopping off): NDCG@10 on train AND held-out of the
+        # rolled-back model (LambdaMART.java:253-265), next to what the CPU oracle ended with on the same inputs (tools/long_parity.py follows the two
+        # side by side for all 1000 rounds -- ~25 minutes of box time -- and its last line is committed)
+        Xh, labh, qh = synth.make_heldout("c1")
+        g1 = N.Trainer(n_trees=args.c1_trees, n_leaves=l1, device=local_rank, early_stop_rounds=1 << 30)
+        g1.set_train(X1, lab1, qoff1)
+        g1.set_validation(Xh, labh, qh)
+        g1.init()
+        g1.boost_rounds_async(args.c1_trees)
+        g1.sync()
+        tr_g, ho_g = g1.finish()
+        lp = {}
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_long_parity_c1.json")) as fh:
+                lp = json.loads(fh.read())
+        except Exception:       # noqa: BLE001
+            lp = {}
+        same_run = bool(lp) and lp.get("rounds") == args.c1_trees
+        out["config"]["c1_heldout_run"] = {
+            "workload": "configs[1] with %d held-out documents in %d lists passed through rl_set_validation, %d trees, early stopping off" % (len(labh), len(qh) - 1, args.c1_trees),
+            "ndcg10_train_gpu": tr_g, "ndcg10_heldout_gpu": ho_g, "trees_kept_gpu": g1.num_trees(),
+            "ndcg10_train_oracle": lp.get("ndcg10_train_oracle") if same_run else None, "ndcg10_heldout_oracle": lp.get("ndcg10_heldout_oracle") if same_run else None,
+            "first_divergent_round": lp.get("first_divergent_round") if same_run else None, "rounds_compared_identical": lp.get("rounds_compared_identical") if same_run else None,
+            "splits_compared": lp.get("splits_compared") if same_run else None, "splits_storing_another_candidate": lp.get("splits_storing_another_candidate") if same_run else None,
+            "oracle_source": "profiles/r05_long_parity_c1.json (tools/long_parity.py c1 1000: GPU and oracle side by side, every round compared)" if same_run else None,
+            "heldout_abs_diff_vs_oracle": (abs(ho_g - lp["ndcg10_heldout_oracle"]) if same_run else None),
+            "train_abs_diff_vs_oracle": (abs(tr_g - lp["ndcg10_train_oracle"]) if same_run else None)}
+        del g1, Xh
 
     if world == 1 and args.ns_rounds > 0 and args.shape == "c2" and not args.java_order:
         # the north star's own list length ("~10 docs/query") at the same size: SURVEY.md 8d asks for both variants

@@ -160,3 +160,18 @@ def make_shard(n_docs, n_features=136, kind="mslr", rank=0, world=1, seed_offset
         X = features(d1 - d0, n_features, d0, SEED_DATA + seed_offset, sparse=sp)
     lab, _ = labels_from(X, d0, SEED_LABEL + seed_offset, cuts=cuts)
     return X, lab, (qoff[qb:qe + 1] - qoff[qb]).astype(np.int32), int(len(qoff) - 1)
+
+
+def make_heldout(shape, frac=0.2):
+    """A held-out set for a SHAPES entry: documents n_docs .. n_docs (1 + frac) of the shape's own generator (the stream simply continues past the
+    training documents), labelled with the cuts of the training prefix (as make_shard labels), lists of the shape's kind from another size stream.
+    Used by tools/long_parity.py and bench.py (NDCG@10 on train AND held-out, GPU vs oracle)."""
+    n_docs, n_feat, kind, _, _ = SHAPES[shape]
+    nv = int(n_docs * frac)
+    sp = kind == "yahoo"
+    ns = min(262144, n_docs)
+    _, cuts = labels_from(features(ns, n_feat, 0, SEED_DATA, sparse=sp), 0, SEED_LABEL)
+    Xv = features(nv, n_feat, n_docs, SEED_DATA, sparse=sp)
+    labv, _ = labels_from(Xv, n_docs, SEED_LABEL, cuts=cuts)
+    qv = query_sizes(nv, kind, SEED_QSIZE + 77)
+    return Xv, labv, qv

@@ -12,7 +12,7 @@ own and the final train and held-out NDCG@10 of both are printed (MetricScorer.s
 usage (GPU box; ~0.7 s a round at c1 and ~2.2 s at c2 on the box's host threads, i.e. 12 + 11 minutes):
     python tools/long_parity.py c1 1000
     python tools/long_parity.py c2 300
-The last line is one JSON object (bench.py --long-parity-json reads it into config.long_parity)."""
+The last line is one JSON object; the c1 x 1000 one is committed as profiles/r05_long_parity_c1.json and read by bench.py (config.c1_heldout_run)."""
 import json
 import os
 import sys
@@ -30,17 +30,7 @@ from ranklib_amd import _native as N, synth  # noqa: E402
 from tree_equiv import assert_equivalent  # noqa: E402
 
 
-def held_out(shape, frac=0.2):
-    """documents n_docs .. n_docs (1 + frac) of the shape's own generator, labelled with the cuts of the training prefix, lists of the shape's kind"""
-    n_docs, n_feat, kind, _, _ = synth.SHAPES[shape]
-    nv = int(n_docs * frac)
-    sp = kind == "yahoo"
-    ns = min(262144, n_docs)
-    _, cuts = synth.labels_from(synth.features(ns, n_feat, 0, synth.SEED_DATA, sparse=sp), 0, synth.SEED_LABEL)      # as make_shard cuts them
-    Xv = synth.features(nv, n_feat, n_docs, synth.SEED_DATA, sparse=sp)
-    labv, _ = synth.labels_from(Xv, n_docs, synth.SEED_LABEL, cuts=cuts)
-    qv = synth.query_sizes(nv, kind, synth.SEED_QSIZE + 77)
-    return Xv, labv, qv
+held_out = synth.make_heldout
 
 
 def main():
