@@ -189,7 +189,7 @@ def bench_infer(args):
                    "mean_node_visits_per_tree": visits, "node_visits_per_s": docs_per_s * nt * visits,
                    "model_parse_seconds": round(t_load, 2)},
         "roofline": {
-            # the walk is bound by instruction issue, not by bytes: a chain step is 5 vector-ALU + 2 LDS wave-instructions for 64 lanes.
+            # the walk is bound by instruction issue, not by bytes: a chain step is 5 vector-ALU + 2 LDS wave-instructions for 64 lanes (HISTORY.md 4.8).
             # peak = what the four SIMDs of a CU issue if they did nothing else: 4 SIMDs x 64 lanes / (5 VALU x 4 cycles) lane-steps per CU and clock.
             "kernel": "rl::k_model_eval_tiled", "bound": "valu_issue",
             "achieved": docs_per_s / world * nt * walk_steps / (256 * 2.4e9), "peak": 4 * 64 / (5 * 4.0), "unit": "lane-steps per CU and clock",
@@ -254,6 +254,24 @@ def respawn(n):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.stdout.flush()
     os.execvpe(sys.executable, cmd, env)
+
+
+def scaling_model(docs_per_rank, world, steps_tree=10.8, ar_bytes=None):
+    """MODELLED (never fitted to a multi-GPU run) milliseconds per round of a sharded run, from the one-GPU c2 measurements of round 5
+    (profiles/r05*_c2_kernel_stats.txt): kernels whose work is per document scale with the shard; a growth step of the sharded path (count + scatter
+    partition, child histograms, limb reduce, all-reduce, finish + bookkeeping: the round-4 kernels) keeps its launch / latency floor and pays one
+    all-reduce (assumed 20 us + bytes at 40 GB/s effective ring bandwidth per rank over xGMI); the float chain of the largest leaf has one owner."""
+    share = docs_per_rank / 3.77e6
+    if ar_bytes is None:
+        ar_bytes = 2.2 * 559e3          # ~2.2 slots of 559 KB per step on average at F = 136
+    t_doc = (0.42 + 0.13 + 0.30 + 0.015) * share                   # lambdas, ranking, root pass + finish, score update
+    t_step = steps_tree * (0.075 + 0.048 * share + 0.020 + ar_bytes / 40e9 * 1e3)
+    # leaf sums: a leaf's float chain is one sequence with one owner rank; the largest leaf holds ~60 % of ALL documents early in training, so its owner
+    # evaluates 0.6 x (documents of the whole job) whatever the rank count; + the exchange and its host hand-over when sharded
+    t_leaf = 0.27 * max(share, 0.6 * share * world) + (0.15 if world > 1 else 0.0)
+    return {"modelled_ms_per_round": t_doc + t_step + t_leaf, "modelled_rounds_per_s": 1000.0 / (t_doc + t_step + t_leaf), "world": world,
+            "docs_per_rank": docs_per_rank, "growth_steps_per_tree": steps_tree, "allreduce_bytes_per_call": ar_bytes,
+            "note": "modelled = per-document kernels x shard share + growth steps x (launch floor + shard's histogram work + one all-reduce) + leaf sums"}
 
 
 def main():
@@ -457,7 +475,7 @@ def main():
             lds_cal = None
     pmc = None if (args.no_pmc or world != 1) else live_pmc(args.shape)
     lds_atomics = None
-    try:      # what the root pass is actually bound by: one ds_add_u64 per (document, feature) outside the feature's most populated bin
+    try:      # what the root pass is actually bound by (HISTORY.md 4.1): one ds_add_u64 per (document, feature) outside the feature's most populated bin
         cnt_cum, nb_ = g.array("ROOT_COUNT").astype(np.int64), g.array("NBINS")
         lds_atomics = 0.0
         for f_ in range(n_feat):
@@ -521,7 +539,7 @@ def main():
                                    "%.1f x FETCH_SIZE + WRITE_SIZE (factors: profiles/r02_fetch_calibration.txt)" % FETCH_FACTOR_GATHER32) if pmc else None,
                 "note": "algorithmic bytes (SURVEY.md 8d) = documents of the accumulated (smaller) children x (F*2 B bin ids + 8 B lambda + 4 B sample id); HIP events around "
                         "every growth step's launch over %d extra rounds (the empty launches of finished trees count as launches); the launches are short and mostly "
-                        "latency-bound (DESIGN.md 4.1, 4.2): most of a step's time is neither bytes nor atomics" % args.node_rounds,
+                        "latency-bound (HISTORY.md 4.1, 4.2): most of a step's time is neither bytes nor atomics" % args.node_rounds,
                 "root_pass": root_entry,
             }
         else:       # (--no-timing / --node-rounds 0: only the root pass was timed)
@@ -542,27 +560,24 @@ def main():
                                                      "note": "payload handed to the transport by this rank per round: histogram limbs per growth step (all-reduce); lambda / weight of the "
                                                              "leaves this rank owns, from the ranks that hold their documents (all-to-all); per-query metric values and leaf tables (all-gather)"}
         # DESIGN.md 6's latency model of a sharded round next to what this run measured: the day several GPUs run this line the model is tested.
-        # Constants are the one-GPU c2 measurements of round 4 (profiles/r04*): per-document work scales with the shard, a growth step keeps its
-        # launch / latency floor and gains one all-reduce (assumed 20 us + bytes at 40 GB/s effective ring bandwidth per rank over xGMI).
         steps_tree = float(gs[0]) / max(int(gs[3]), 1)
-        share = float(X.shape[0]) / 3.77e6
         ar_bytes = ds[1] / max(ds[0], 1.0)
-        t_doc = (0.42 + 0.14 + 0.25 + 0.07 + 0.04) * share            # lambdas, ranking, root pass, score update, quantisation (ms at 3.77 M documents)
-        t_step = steps_tree * (0.060 + 0.045 * share + 0.020 + ar_bytes / 40e9 * 1e3)      # latency floor of 5 launches + the shard's histogram work + collective
-        t_leaf = 0.30 * max(share, 0.6 / world + 0.4 * share) + 0.15    # float chains of the owned leaves (the largest leaf has one owner) + the exchange and its host hand-over
-        out["config"]["scaling_model"] = {"modelled_ms_per_round": t_doc + t_step + t_leaf, "measured_ms_per_round": 1000.0 * elapsed / args.steps,
-                                          "growth_steps_per_tree": steps_tree, "allreduce_bytes_per_call": ar_bytes,
-                                          "note": "modelled = per-document kernels x shard share + growth steps x (launch floor + shard's histogram work + one all-reduce) + leaf sums; "
-                                                  "constants from the one-GPU c2 profile (DESIGN.md 6); never fitted to a multi-GPU run"}
+        out["config"]["scaling_model"] = dict(scaling_model(float(X.shape[0]), world, steps_tree, ar_bytes), measured_ms_per_round=1000.0 * elapsed / args.steps)
         if not weak:
             out["config"]["scaling_note"] = ("strong scaling of %d documents is latency-bound: a 31-leaf tree is a chain of ~11 dependent growth steps, each with one "
                                              "all-reduce when sharded, whatever the shard size (DESIGN.md 6); --scaling weak keeps the documents per GPU fixed" % n_docs)
+    if world == 1 and args.shape == "c2":
+        # what DESIGN.md 6's model says about 2 / 4 / 8 GPUs -- MODELLED, printed so that the first multi-GPU run has something to be held against
+        out["config"]["scaling_model"] = {"strong_%d" % n: scaling_model(n_docs / n, n) for n in (2, 4, 8)}
+        out["config"]["scaling_model"].update({"weak_%d" % n: scaling_model(float(n_docs), n) for n in (2, 4, 8)})
+        out["config"]["scaling_model"]["note"] = ("MODELLED, never measured (no multi-GPU box): strong = this data set over n GPUs, weak = this many documents PER GPU; "
+                                                  "rounds/s of the whole job; aggregate document-rounds/s under weak scaling = n x docs_per_rank x rounds/s")
     if sustained is not None:
         out["config"]["sustained_rounds_per_s"] = sustained
         out["config"]["sustained_over_rounds"] = args.sustain
     ts = g.array("TIE_STATS")
     out["config"]["tie_break"] = {
-        "mode": "lazy Java-order (exact ties re-decided in the reference's summation order, DESIGN.md 4.13; sharded runs gather the chain nodes and do the same)"
+        "mode": "lazy Java-order (exact ties re-decided in the reference's summation order, HISTORY.md 4.13; sharded runs gather the chain nodes and do the same)"
                 if (not args.java_order and not args.first_tie) else
                 ("strict: every candidate from the Java-order histogram" if args.java_order else "first candidate in scan order (--first-tie)"),
         "resolutions": int(ts[0]), "nodes": int(ts[1]), "chain_documents": int(ts[3]), "host_ms": float(ts[4]) / 1e3,
@@ -592,8 +607,8 @@ def main():
         g1.set_train(X1, lab1, qoff1)
         g1.set_validation(Xh, labh, qh)
         g1.init()
-        g1.boost_rounds_async(args.c1_trees)
-        g1.sync()
+        for _ in range(args.c1_trees):          # (a validation set: round by round -- the early-stop decision is the host's, LambdaMART.java:240-250)
+            g1.boost_round(want_tree=False)
         tr_g, ho_g = g1.finish()
         lp = {}
         try:

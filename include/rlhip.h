@@ -68,7 +68,7 @@ enum {                                  /* rl_params.flags */
     RL_FLAG_SERIAL_CHAIN = 4,           /* evaluate the float running sums with the literal serial kernel instead of
                                            the exact parallel scheme (same results; for cross-checks) */
     RL_FLAG_FIRST_TIE = 32,             /* exact ties between split candidates keep the first one in scan order instead of being re-decided in the Java's
-                                           summation order (the lazy tie-break, DESIGN.md 4.13: default, also for sharded runs; never with feature sampling).
+                                           summation order (the lazy tie-break, HISTORY.md 4.13: default, also for sharded runs; never with feature sampling).
                                            Faster where nodes are tiny or columns sparse; the trees differ from the reference's only in the stored threshold
                                            inside an empty-bin plateau / in which of two equivalent features is named. */
     RL_FLAG_JAVA_ORDER = 16             /* strict mode: split gains and node deviances come from the f64 histogram RankLib itself
@@ -284,7 +284,7 @@ enum {
     RL_ARR_SPARSE_INFO = 19,    /* int64[8]: 16-feature groups whose root histogram comes from sparse-column entry lists (rl_csc.inc), entries,
                                    groups read as dense rows, live columns in the sparse groups; groups whose child passes read compact rows (0 = off),
                                    their entries (cells outside the mode bins), rows with more than eight entries (dense fallback), row stride */
-    RL_ARR_TIE_STATS = 21,      /* int64[10] cumulative, the lazy Java-order tie-break: resolutions run by the host (stalled trees + batches), nodes
+    RL_ARR_TIE_STATS = 21,      /* int64[10] cumulative, the lazy Java-order tie-break (HISTORY.md 4.13): resolutions run by the host (stalled trees + batches), nodes
                                    whose tied best split was re-decided in the Java's summation order, nodes and documents of the derivation chains that were summed,
                                    host microseconds spent resolving, chain segments evaluated speculatively, candidate-window misses, segments run serially,
                                    [8] of the resolutions the batches at the end of a tree (deferred ties), [9] trees grown a second time (a deferred tie over
@@ -309,7 +309,7 @@ int rl_debug_float_chain(int32_t device, const double *x, int64_t n, const int64
 int rl_bin_stride(const rl_trainer *t, int32_t *stride);
 /* Histogram features of an initialised trainer and the column (0-based position in feature_ids) behind each.  Equal to the data set's features
  * unless a threshold table has more than 4095 entries (-tc -1 on a column with that many distinct values, or -tc N > 4095: learning/tree/
- * LambdaMART.java:135-149): such a feature is split into runs of 4094 thresholds and RL_ARR_NBINS / THRESHOLDS / BINS /
+ * LambdaMART.java:135-149): such a feature is split into runs of 4094 thresholds (HISTORY.md 10.4) and RL_ARR_NBINS / THRESHOLDS / BINS /
  * ROOT_* are shaped by THIS count.  columns may be NULL; at most cap entries are written. */
 int rl_hist_features(const rl_trainer *t, int32_t *n, int32_t *columns, int32_t cap);
 int rl_quant_exponent(const rl_trainer *t, int32_t *e);   /* q = rint(lambda * 2^e) in the last round */

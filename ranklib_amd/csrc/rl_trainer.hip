@@ -102,7 +102,9 @@ struct rl_trainer {
     int32_t round = 0;          // rounds enqueued so far
     // growth progress reported by the device (Ctx::progress): the host keeps at most `step_ahead` growth steps in flight and
     // stops enqueuing steps of a finished tree; 0 = enqueue all L-1 steps blindly
-    unsigned long long *h_progress = nullptr; uint32_t tree_seq = 0; int32_t step_ahead = 3;
+    unsigned long long *h_progress = nullptr; uint32_t tree_seq = 0; int32_t step_ahead = 1;       // (1: c2 409.5 -> 411.7 rounds/s against 3, profiles/r05g_ab_step_ahead_c2.txt -- fewer empty steps behind a finished tree)
+    int32_t dist_ahead = 0;     // sharded runs: growth steps enqueued beyond the last one whose bookkeeping the host has seen -- 0: every enqueued step has work (an empty
+                                // step still costs its all-reduce on every rank); RLHIP_DIST_STEP_AHEAD
     unsigned long long chain_seq = 0; std::vector<void *> pinned;     // chain pass tags; pinned words of the chains (freed in rl_destroy)
     int32_t synced_rounds = 0;
     long long tie_stalls = 0, tie_nodes = 0, tie_chain_nodes = 0, tie_chain_docs = 0;      // lazy tie-break (rl_tie.inc): resolutions run, nodes resolved, chain nodes / documents summed
@@ -457,7 +459,8 @@ static void launch_hist(const Ctx &c, int gx, int gy, size_t lds, hipStream_t s,
     // step's chunks (k_hist), about one resident set of blocks (3 per CU)
     static const int grid_blocks = getenv("RLHIP_HIST_GRID") ? atoi(getenv("RLHIP_HIST_GRID")) : 1024;
     // (balanced steps -- balance_slots -- want exactly balance_target rows: block row r then works through the chunks r, r + balance_target, ..)
-    const auto bounded = [&](int gxx) { return ROOT ? ((gy + 7) & ~7) : (c.balance && c.n_ranks == 1 && !getenv("RLHIP_HIST_GRID")) ? std::min((gy + 7) & ~7, c.balance_target)
+    static const bool grid_env = getenv("RLHIP_HIST_GRID") != nullptr;        // (cached: this runs thousands of times a second)
+    const auto bounded = [&](int gxx) { return ROOT ? ((gy + 7) & ~7) : (c.balance && c.n_ranks == 1 && !grid_env) ? std::min((gy + 7) & ~7, c.balance_target)
                                                                       : std::min((gy + 7) & ~7, std::max(8, ((grid_blocks + gxx - 1) / gxx + 7) & ~7)); };
     // (RLHIP_HIST_LDSPAD: extra dynamic LDS per child-pass block -- 28 KB caps a CU at two blocks; a measuring aid)
     static const size_t lds_pad = getenv("RLHIP_HIST_LDSPAD") ? (size_t)atoi(getenv("RLHIP_HIST_LDSPAD")) : 0;
@@ -1069,10 +1072,11 @@ static int enqueue_round(rl_trainer *t)
                 continue;
             }
         }
-        if (throttle && it >= t->step_ahead) {
+        const int ahead = t->dist ? t->dist_ahead : t->step_ahead;
+        if (throttle && it >= ahead) {
             // wait (bounded) until growth step it - step_ahead has been selected, then look at the tree's done flag.  Purely a
             // scheduling hint: on a timeout the remaining steps are enqueued blindly, which is always correct.
-            const unsigned long long want = ((unsigned long long)t->tree_seq << 32) | ((unsigned long long)(unsigned)(it - t->step_ahead) << 1);
+            const unsigned long long want = ((unsigned long long)t->tree_seq << 32) | ((unsigned long long)(unsigned)(it - ahead) << 1);
             const auto finished = [&](unsigned long long w) { return (w >> 32) == t->tree_seq && (w & 1); };
             unsigned long long w = __atomic_load_n(t->h_progress, __ATOMIC_ACQUIRE);
             if (t->dist) {
@@ -1090,15 +1094,15 @@ static int enqueue_round(rl_trainer *t)
                         // the wait ends when THIS rank's device finishes a growth step, which needs every other rank's share of the step's
                         // collective: a rank that died or fell behind for good must surface as an error here, not as a hang
                         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0w).count() > t->dist_timeout_s)
-                            return fail(RL_ERR_COMM, "timed out after " + std::to_string((int)t->dist_timeout_s) + " s waiting for growth step " + std::to_string(it - t->step_ahead) +
+                            return fail(RL_ERR_COMM, "timed out after " + std::to_string((int)t->dist_timeout_s) + " s waiting for growth step " + std::to_string(it - ahead) +
                                                      " of tree " + std::to_string(t->tree_seq) + " (a rank of the job is missing from a collective?)");
                     }
                 }
                 const int step_w = (int)((unsigned)(w & 0x3fffffffull) >> 1);
-                if (finished(w) && step_w <= it - t->step_ahead) { saw_end = true; defer_seen = ((w >> 30) & 1ull) != 0; break; }
+                if (finished(w) && step_w <= it - ahead) { saw_end = true; defer_seen = ((w >> 30) & 1ull) != 0; break; }
                 // a stalled tree (rl_tie.inc): the word keeps the step at which it stalled, so -- as for the end of the tree -- every rank acts on
                 // it at the same `it`, after the same number of (empty) steps and their collectives
-                if (stalled(w) && step_w <= it - t->step_ahead) {
+                if (stalled(w) && step_w <= it - ahead) {
                     bool ended = false;
                     int rcs = after_stall(ended);
                     if (rcs) return rcs;
@@ -1110,7 +1114,7 @@ static int enqueue_round(rl_trainer *t)
                 // (bits 30 / 31 of the low word are flags: the step is compared field by field)
                 const auto behind = [&](unsigned long long v) {
                     if ((v >> 32) != t->tree_seq) return true;                   // still the previous tree's word
-                    return (unsigned)((v & 0x3fffffffull) >> 1) < (unsigned)(it - t->step_ahead) && !(v & 1) && !((v >> 31) & 1);
+                    return (unsigned)((v & 0x3fffffffull) >> 1) < (unsigned)(it - ahead) && !(v & 1) && !((v >> 31) & 1);
                 };
                 if (behind(w)) {
                     const auto t0 = std::chrono::steady_clock::now();
@@ -1700,6 +1704,16 @@ int rl_init(rl_trainer *t)
     RL_HIP(hipMemcpy(h_over.data(), fs.overflow, F * sizeof(int32_t), hipMemcpyDeviceToHost));
     RL_HIP(hipMemcpy(&h_bad, fs.bad, sizeof(int32_t), hipMemcpyDeviceToHost));
     if (h_bad) return fail(RL_ERR_INVALID, "NaN feature value (resolve NaN to 0 as DataPoint.getFeatureValue does)");
+    if (nT == 1) {
+        // -tc 1 on a column that overflows into the step table [fmin, MAX_VALUE]: a +Infinity value is above every threshold, and the Java's binning loop
+        // (FeatureHistogram.java:88-107) then never assigns it -- stMap stays 0 and the counts exclude it, i.e. node counts that do not add up.  Not
+        // reproduced (the binning here would put it into the last bin and count it): refused, with the reason
+        std::vector<uint32_t> h_max(F);
+        RL_HIP(hipMemcpy(h_max.data(), fs.maxkey, F * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (int f = 0; f < F; f++)
+            if (h_over[f] && h_max[f] == 0xFF800000u)      // float_key(+Infinity)
+                return fail(RL_ERR_UNSUPPORTED, "-tc 1 with a +Infinity value in feature column " + std::to_string(f) + ": RankLib leaves such documents out of the histogram counts (unsupported)");
+    }
     const bool want_big = (nT == -1 || nT > kMaxBins - 1);         // tables of more than 4 095 entries are possible
     const int TS0 = fs.limit + 1;
     float *thr0 = nullptr; int32_t *d_nthr = nullptr;
@@ -1729,6 +1743,36 @@ int rl_init(rl_trainer *t)
             std::vector<float> vals(colv);
             std::sort(vals.begin(), vals.end());
             vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+            if (t->dist) {
+                // sharded: the table is built from the distinct values of the column over ALL ranks (LambdaMART.java:108-150 walks one sorted list of every
+                // sample).  Every rank contributes its own sorted distinct values -- counts first, then the values padded to the largest count -- and merges
+                // what it receives; the overflow flags were all-reduced above, so the ranks take this branch for the same columns in the same order.
+                const int R = t->n_ranks;
+                int32_t *d_cnt = nullptr, *d_cnts = nullptr;
+                RL_HIP(hipMalloc((void **)&d_cnt, sizeof(int32_t))); RL_HIP(hipMalloc((void **)&d_cnts, (size_t)R * sizeof(int32_t)));
+                const int32_t mycnt = (int32_t)vals.size();
+                RL_HIP(hipMemcpy(d_cnt, &mycnt, sizeof(int32_t), hipMemcpyHostToDevice));
+                int rcd = t->dist->allgather(d_cnt, d_cnts, sizeof(int32_t), s);
+                std::vector<int32_t> cnts((size_t)R);
+                if (!rcd) { RL_HIP(hipStreamSynchronize(s)); RL_HIP(hipMemcpy(cnts.data(), d_cnts, (size_t)R * sizeof(int32_t), hipMemcpyDeviceToHost)); }
+                (void)hipFree(d_cnt); (void)hipFree(d_cnts);
+                if (rcd) return rcd;
+                const size_t mx = (size_t)*std::max_element(cnts.begin(), cnts.end());
+                float *d_v = nullptr, *d_all = nullptr;
+                RL_HIP(hipMalloc((void **)&d_v, std::max<size_t>(mx, 1) * sizeof(float))); RL_HIP(hipMalloc((void **)&d_all, std::max<size_t>(mx, 1) * R * sizeof(float)));
+                RL_HIP(hipMemset(d_v, 0, std::max<size_t>(mx, 1) * sizeof(float)));
+                RL_HIP(hipMemcpy(d_v, vals.data(), vals.size() * sizeof(float), hipMemcpyHostToDevice));
+                rcd = t->dist->allgather(d_v, d_all, std::max<size_t>(mx, 1) * sizeof(float), s);
+                std::vector<float> all(std::max<size_t>(mx, 1) * R);
+                if (!rcd) { RL_HIP(hipStreamSynchronize(s)); RL_HIP(hipMemcpy(all.data(), d_all, all.size() * sizeof(float), hipMemcpyDeviceToHost)); }
+                (void)hipFree(d_v); (void)hipFree(d_all);
+                if (rcd) return rcd;
+                vals.clear();
+                for (int r = 0; r < R; r++) vals.insert(vals.end(), all.begin() + (size_t)r * std::max<size_t>(mx, 1), all.begin() + (size_t)r * std::max<size_t>(mx, 1) + cnts[r]);
+                std::sort(vals.begin(), vals.end());
+                vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+                if (!vals.empty()) { fmin = vals.front(); fmax = vals.back(); }
+            }
             std::vector<float> &tab = big[f];
             if (nT == -1 || (long long)vals.size() <= (long long)nT) { tab = vals; tab.push_back(3.4028234663852886e38f); }      // :135-140
             else {                                                                                                              // :141-149
@@ -1752,7 +1796,6 @@ int rl_init(rl_trainer *t)
         RL_HIP(hipMemsetAsync(d_thr, 0, (size_t)F * TS * sizeof(float), s));
         RL_HIP(hipMemcpy2DAsync(d_thr, TS * sizeof(float), thr0, TS0 * sizeof(float), TS * sizeof(float), F, hipMemcpyDeviceToDevice, s));
     } else {
-        if (t->dist) return fail(RL_ERR_UNSUPPORTED, "a threshold table of more than 4095 entries with multi-GPU training (the distinct values of a column would have to be merged over the ranks)");
         if (t->p.flags & RL_FLAG_JAVA_ORDER) return fail(RL_ERR_UNSUPPORTED, "a threshold table of more than 4095 entries with RL_FLAG_JAVA_ORDER (the Java's prefix over ALL bins of a feature is one f64 chain)");
         std::vector<float> h_thr0((size_t)F * TS0);
         RL_HIP(hipMemcpy(h_thr0.data(), thr0, h_thr0.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -1909,7 +1952,8 @@ int rl_init(rl_trainer *t)
         const char *e = getenv("RLHIP_CROWS");
         const int force = e ? atoi(e) : -1;
         bool maybe = force == 1;
-        if (force < 0 && TS <= kHistLdsStride && c.sub == 16) {
+        if (c.any_runs) maybe = false;      // (launch_hist takes the RUNS instantiation on such data, which reads dense rows: the compact rows would be built and never read -- ADVICE r04)
+        if (force < 0 && TS <= kHistLdsStride && c.sub == 16 && !c.any_runs) {
             // cheap look first (the exact root counts are on the device already): dense data -- more than 5 cells a row outside the mode bins on
             // average -- never builds the rows (a gigabyte of transient memory and 8 ms at the MSLR-WEB30K shape)
             std::vector<int32_t> hc((size_t)F * TS), hm((size_t)F);
@@ -2123,6 +2167,7 @@ int rl_init(rl_trainer *t)
     RL_HIP(hipMemset(c.st, 0, sizeof(TreeState)));
     t->tree_seq = 0;
     if (const char *e = getenv("RLHIP_STEP_AHEAD")) t->step_ahead = std::max(0, atoi(e));     // tuning knob
+    if (const char *e = getenv("RLHIP_DIST_STEP_AHEAD")) t->dist_ahead = std::max(0, atoi(e));
     if (const char *e = getenv("RLHIP_DIST_TIMEOUT_S")) t->dist_timeout_s = std::max(1.0, atof(e));
     // the progress word is an optimisation: without host-visible coherent memory the host simply enqueues every step
     c.progress = nullptr;

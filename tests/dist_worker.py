@@ -20,6 +20,7 @@ def main():
     out_path, n_docs, n_feat, kind, seed, leaves, rounds = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
     ranker, metric, k = (sys.argv[8], sys.argv[9], int(sys.argv[10])) if len(sys.argv) > 10 else ("LAMBDAMART", "NDCG", 10)
     # "valid": sharded validation set + early stopping; "rccl": RCCL transport; "noa2a": a transport without an all-to-all (emulated with all-gathers);
+    # "tcm1": -tc -1 (every distinct value a threshold: the continuous columns get tables of more than 4095 entries, split into virtual features);
     # "leafm1": -leaf -1 with min leaf support 40; "qrel": external judgments (a third of the lists get an ideal DCG of their own times 1.5)
     opts = sys.argv[11].split(",") if len(sys.argv) > 11 else []
     dist.init_process_group("gloo")
@@ -35,7 +36,7 @@ def main():
     if "perdev" in opts:
         torch.cuda.set_device(device)
     g = N.Trainer(n_trees=rounds, n_leaves=-1 if "leafm1" in opts else leaves, ranker=ranker, metric=metric, metric_k=k, early_stop_rounds=estop,
-                  min_leaf_support=40 if "leafm1" in opts else 1, device=device)
+                  min_leaf_support=40 if "leafm1" in opts else 1, device=device, n_threshold=-1 if "tcm1" in opts else 256)
     g.set_train(Xs, ls, qs)
     if "qrel" in opts:       # -qrel: every rank passes the judgments of ITS lists (tests/test_gpu_dist.py external_judgments is the same rule)
         qb, qe = D.partition_queries(qoff, world)[rank]

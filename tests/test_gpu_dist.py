@@ -27,7 +27,7 @@ def single(n_docs, n_feat, kind, seed, leaves, rounds, dist_mode=None, ranker="L
     # default flags on both sides: sharded runs re-decide exact ties in the Java's summation order as well (the members' values are gathered,
     # every rank evaluates the same global chains) -- k shards must equal one shard in the stored (feature, threshold) pairs too
     g = N.Trainer(n_trees=rounds, n_leaves=-1 if "leafm1" in opts else leaves, ranker=ranker, metric=metric, metric_k=k,
-                  min_leaf_support=40 if "leafm1" in opts else 1)
+                  min_leaf_support=40 if "leafm1" in opts else 1, n_threshold=-1 if "tcm1" in opts else 256)
     g.set_train(X, lab, qoff)
     if "qrel" in opts:       # as tests/dist_worker.py
         qi = np.arange(len(qoff) - 1)
@@ -105,19 +105,20 @@ def test_k_shards_equal_one_shard(world, ranker, metric, k, cfg, tmp_path):
     st = z["dist_stats"].astype(np.float64)
     if cfg is CFG_TIES:      # the tie-break ran sharded: resolutions, and exchanges of the chain nodes' values counted apart from the per-round pattern
         assert z["tie_stats"][0] > 0 and st[6] > 0 and st[7] > 0, (z["tie_stats"], st)
-    assert st[4] == rounds + int(z["tie_stats"][9]) and st[5] > 0          # one leaf-owner exchange per round -- and one more for a tree that was grown a second time (DESIGN.md 4.13 c)
+    assert st[4] == rounds + int(z["tie_stats"][9]) and st[5] > 0          # one leaf-owner exchange per round -- and one more for a tree that was grown a second time (HISTORY.md 4.13 c)
     assert st[5] / st[4] <= 16.0 * CFG[0] * (world - 1) / world * 0.95, st
     # (st[3], the all-gather bytes, also holds rl_init's one-off exchange of the distinct-value sets; the per-round figure is checked through
     # bench.py's counters in test_bench_entry_starts_its_own_ranks)
 
 
 @pytest.mark.parametrize("world,metric,k,opt", [(2, "NDCG", 10, "noa2a"), (3, "NDCG", 10, "leafm1"), (2, "NDCG", 10, "qrel"), (3, "MAP", 0, "qrel"),
-                                                (2, "NDCG", 10, "dupcols"), (3, "NDCG", 10, "dupcols,regrow")])
+                                                (2, "NDCG", 10, "dupcols"), (3, "NDCG", 10, "dupcols,regrow"), (2, "NDCG", 10, "tcm1"), (3, "NDCG", 10, "tcm1")])
 def test_sharded_options(world, metric, k, opt, tmp_path):
     """noa2a: a host transport WITHOUT an all-to-all (the exchange is emulated with all-gathers); leafm1: -leaf -1 (the leaf budget comes from the
     GLOBAL document count); qrel: external relevance judgments, every rank passing the entries of its own lists; dupcols: duplicated columns -- ties
     over several features that share one cut are deferred to the per-tree batch, every rank checks the cuts on its own documents and the verdict
-    is all-reduced (regrow: forced to fail, all ranks grow the tree again) -- each equals the one-GPU run"""
+    is all-reduced (regrow: forced to fail, all ranks grow the tree again); tcm1: -tc -1, threshold tables of more than 4095 entries (the ranks merge
+    their distinct values at rl_init and split the tables into the same virtual features: LambdaMART.java:135-140 has no limit) -- each equals the one-GPU run"""
     cfg = (9000, 16, "mslr", 5, 10, 4)
     ref = single(*cfg, metric=metric, k=k, opts=tuple(opt.split(",")))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")

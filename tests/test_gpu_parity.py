@@ -1071,7 +1071,7 @@ def test_wide_and_deep_shapes_match_the_oracle(F, n, leaves):
 @pytest.mark.parametrize("split", ["0", "1"])
 def test_fused_and_two_launch_finish_give_the_same_trees(split, monkeypatch):
     """the finish of a growth step is one launch (the last block runs the bookkeeping) or, on wide data, two (k_hist_finish_wide + k_select,
-    DESIGN.md 4.10); RLHIP_FIN_SPLIT forces either on any data.  Both against the oracle, with a validation set, on data whose trees need ties
+    HISTORY.md 4.10); RLHIP_FIN_SPLIT forces either on any data.  Both against the oracle, with a validation set, on data whose trees need ties
     resolved (the stalled / deferred paths re-enter the bookkeeping from another kernel)"""
     monkeypatch.setenv("RLHIP_FIN_SPLIT", split)
     X, lab, qoff = make(5000, 24, "mslr", 77)

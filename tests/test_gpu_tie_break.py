@@ -1,4 +1,4 @@
-"""-m gpu: the lazy Java-order tie-break of the default path (ranklib_amd/csrc/rl_tie.inc).
+"""-m gpu: the lazy Java-order tie-break of the default path (ranklib_amd/csrc/rl_tie.inc, HISTORY.md 4.13).
 
 The parity suites already demand the oracle's stored (feature, threshold) pairs everywhere; these tests aim at the machinery itself: the
 speculative evaluation of long chains against the literal walk, the deferred batch, the first-candidate flag, and the statistics array."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Raw per-block stamps of ONE tree's growth kernels, with the hardware place of every block (stamp 6: XCD << 32 | HW_ID; -DRL_PHASE_CLOCKS build
-selected with RLHIP_LIB): which CU ran which block when -- the load balance of the child-histogram passes.
+selected with RLHIP_LIB): which CU ran which block when -- the load balance of the child-histogram passes (HISTORY.md 10.5).
 usage (GPU box): RLHIP_LIB=... python tools/block_place.py out.npy [shape] [tree]   -> int64 [steps<=16][3 kernels][2048 blocks][8 stamps] (10 ns ticks)"""
 import os
 import sys
