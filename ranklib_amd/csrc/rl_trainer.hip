@@ -112,6 +112,7 @@ struct rl_trainer {
     bool fin_split = false;      // wide data: k_hist_finish_wide + k_select instead of the fused finish (rl_init)
     bool step2 = true;           // k_fin2 (+ k_select2) instead of the fused finish / bookkeeping kernel (rl_step2.inc; RLHIP_STEP2=0: the round-4 kernels)
     long long tie_phase_us[6] = {0, 0, 0, 0, 0, 0};   // RLHIP_TIE_PROF: host microseconds per phase of resolve_ties (printed by rl_destroy)
+    long long chain_calls[2] = {0, 0}, chain_repairs[2] = {0, 0}, chain_timeouts = 0, chain_wait_us = 0;      // RLHIP_CHAIN_PROF: float-chain evaluations [hinted, blind], repair passes enqueued, progress-word time-outs, host microseconds spent waiting for a stitch
     long long tie_regrown = 0;      // trees grown a second time because a deferred tie over several features hid two different cuts (k_tie_verify)
     long long tie_us = 0, tie_spec_segs = 0, tie_spec_miss = 0, tie_spec_serial = 0, tie_spec_repairs = 0;      // host time in resolve_ties; segments evaluated, window misses, serial segments, repair passes
     std::vector<int32_t> h_nthr; std::vector<char> tie_blob;
@@ -380,6 +381,7 @@ static void enqueue_chain(rl_trainer *t, const ChainBufs &b_in, const ChainSourc
     // every stitch pass carries a tag; with a progress word (ChainBufs::h_progress) the host looks at the result of the pass
     // before the last one it enqueued and leaves the remaining repair passes (near-empty launches) away once nothing is open
     const unsigned long long seq = ++t->chain_seq;
+    t->chain_calls[b.h_progress ? 0 : 1]++;
     bool hint = b.h_progress != nullptr && t->step_ahead > 0, clean = false;
     const dim3 cgrid((unsigned)((b.cap_chunks / kChainBlock + kThreads / 64) / (kThreads / 64)), b.A);       // one wavefront per block of kChainBlock chunks
     hipLaunchKernelGGL(k_chain_tables<false>, tgrid, dim3(kThreads), 0, s, b, 0);
@@ -392,9 +394,13 @@ static void enqueue_chain(rl_trainer *t, const ChainBufs &b_in, const ChainSourc
         if (hint) {      // (a repair pass is four launches: none is enqueued before the stitch it would repair has reported)
             const unsigned long long want = (seq << 16) | (unsigned)rep;            // the stitch before repair pass rep (0 = the first stitch)
             unsigned long long w;
-            if (!spin_until(b.h_progress, [&](unsigned long long v) { return (v >> 1) >= want; }, w)) hint = false;
+            const auto tw0 = std::chrono::steady_clock::now();
+            const bool seen = spin_until(b.h_progress, [&](unsigned long long v) { return (v >> 1) >= want; }, w);
+            t->chain_wait_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tw0).count();
+            if (!seen) { hint = false; t->chain_timeouts++; }
             else if ((w >> 17) == seq && !(w & 1)) { clean = true; break; }
         }
+        t->chain_repairs[b.h_progress ? 0 : 1]++;
         hipLaunchKernelGGL(k_chain_pass1<true>, p1grid, dim3(kThreads), 0, s, b);
         hipLaunchKernelGGL(k_chain_recentre, dim3(b.maxseg, b.A), dim3(kScanThreads), 0, s, b);
         hipLaunchKernelGGL(k_chain_tables<true>, tgrid, dim3(kThreads), 0, s, b, 1);
@@ -1191,7 +1197,7 @@ static int enqueue_round(rl_trainer *t)
         } else defer_seen = sth.defer_any != 0;
     }
     // the score update streams over the documents when the leaf sums' gather can leave every document's leaf behind (one GPU, parallel chains, <= 1024 leaves)
-    static const bool stream_env = !(getenv("RLHIP_SCORE_STREAM") && atoi(getenv("RLHIP_SCORE_STREAM")) == 0);
+    const bool stream_env = !(getenv("RLHIP_SCORE_STREAM") && atoi(getenv("RLHIP_SCORE_STREAM")) == 0);        // (read per round: a test switches it)
     const bool stream_scores = stream_env && !t->dist && !(t->p.flags & RL_FLAG_SERIAL_CHAIN) && c.leaf_of != nullptr && c.L > 0 && c.L <= 1024;
     hipLaunchKernelGGL(k_leaf_table, dim3(1), dim3(kThreads), 0, s, c, t->leaf_chain, t->d_seg_buf);
     if (t->p.flags & RL_FLAG_SERIAL_CHAIN) {
@@ -1517,6 +1523,9 @@ void rl_destroy(rl_trainer *t)
     if (getenv("RLHIP_TIE_PROF") && t->tie_stalls > 0)
         fprintf(stderr, "[rlhip] tie-break: %lld resolutions (%lld batches, %lld trees regrown), host us: first read %lld, chains %lld, candidates+lists %lld, sums %lld, finish %lld, total %lld\n",
                 t->tie_stalls, t->tie_batches, t->tie_regrown, t->tie_phase_us[0], t->tie_phase_us[1], t->tie_phase_us[2], t->tie_phase_us[3], t->tie_phase_us[4], t->tie_us);
+    if (getenv("RLHIP_CHAIN_PROF"))
+        fprintf(stderr, "[rlhip] float chains: %lld watched evaluations with %lld repair passes, %lld blind ones with %lld; progress-word time-outs %lld; host waited %lld us for stitches\n",
+                t->chain_calls[0], t->chain_repairs[0], t->chain_calls[1], t->chain_repairs[1], t->chain_timeouts, t->chain_wait_us);
     if (t->stream) { (void)hipStreamSynchronize(t->stream); }
     if (t->side) { (void)hipStreamSynchronize(t->side); (void)hipStreamDestroy(t->side); }
     if (t->ev_lam_fork) (void)hipEventDestroy(t->ev_lam_fork);

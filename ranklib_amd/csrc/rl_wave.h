@@ -56,6 +56,16 @@ __device__ __forceinline__ uint64_t wave_scan_u64(uint64_t v) { RL_WAVE_SCAN_BOD
 __device__ __forceinline__ i128 wave_scan_i128(i128 v) { RL_WAVE_SCAN_BODY(i128, dpp_i128) }
 #undef RL_WAVE_SCAN_BODY
 
+// f64 inclusive scan (the grouping differs from a Kogge-Stone shuffle scan in the last two steps: only for values whose rounding is free to differ --
+// the float chains' prefix GUESSES, rl_chain.inc; adding the +0.0 of a lane without a source is exact)
+__device__ __forceinline__ double wave_scan_f64(double x)
+{
+#define RL_SF(CTRL, RM) x += bits2d(dpp_u64<CTRL, RM>(d2bits(x)));
+    RL_SF(kDppShr1, 0xf) RL_SF(kDppShr2, 0xf) RL_SF(kDppShr4, 0xf) RL_SF(kDppShr8, 0xf) RL_SF(kDppBcast15, 0xa) RL_SF(kDppBcast31, 0xc)
+#undef RL_SF
+    return x;
+}
+
 // wave totals, uniform
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return readlane_u32(wave_scan_u32(v), 63); }
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) { return readlane_u64(wave_scan_u64(v), 63); }

@@ -1068,12 +1068,17 @@ def test_wide_and_deep_shapes_match_the_oracle(F, n, leaves):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("split", ["0", "1"])
-def test_fused_and_two_launch_finish_give_the_same_trees(split, monkeypatch):
-    """the finish of a growth step is one launch (the last block runs the bookkeeping) or, on wide data, two (k_hist_finish_wide + k_select,
-    HISTORY.md 4.10); RLHIP_FIN_SPLIT forces either on any data.  Both against the oracle, with a validation set, on data whose trees need ties
-    resolved (the stalled / deferred paths re-enter the bookkeeping from another kernel)"""
+@pytest.mark.parametrize("step2,split,extras", [("1", "0", "1"), ("1", "0", "0"), ("0", "0", "0"), ("0", "1", "0")])
+def test_fused_and_two_launch_finish_give_the_same_trees(step2, split, extras, monkeypatch):
+    """The second half of a growth step: round 5's two short launches k_fin2 + k_select2 (rl_step2.inc; RLHIP_STEP2=1, the default) or round 4's kernels --
+    one fused launch whose last block runs the bookkeeping or, on wide data, two (k_hist_finish_wide + k_select, HISTORY.md 4.10; RLHIP_FIN_SPLIT forces
+    either).  `extras` switches the other round-5 paths with them: the skipped child histograms of the split that fills the leaf budget and the
+    streaming score update.  All against the oracle, with a validation set, on data whose trees need ties resolved (the stalled / deferred paths
+    re-enter the bookkeeping from another kernel)"""
+    monkeypatch.setenv("RLHIP_STEP2", step2)
     monkeypatch.setenv("RLHIP_FIN_SPLIT", split)
+    monkeypatch.setenv("RLHIP_SKIP_LAST", extras)
+    monkeypatch.setenv("RLHIP_SCORE_STREAM", extras)
     X, lab, qoff = make(5000, 24, "mslr", 77)
     Xv, lv, qv = make(1500, 24, "mslr", 78)
     o, g = pair(X, lab, qoff, n_trees=6, n_leaves=20)
