@@ -302,6 +302,11 @@ enum {
 /* The device's two exp implementations (rho of learning/tree/LambdaMART.java:383) on n arguments: the branch-free one the
  * lambda kernels use and the literal fdlibm e_exp transcription; both must equal StrictMath.exp bit for bit. */
 int rl_debug_exp(const double *x, int32_t n, double *out_fast, double *out_ref);
+/* The lambda kernels' divisions (rl_device.h: div_by_rcp / rcp_newton2 = the compiler's own IEEE expansion without the scaling steps that do
+ * nothing on the operand ranges of learning/tree/LambdaMART.java:383 and metric/NDCGScorer.java:154) against the compiler's division.
+ * den == NULL: out_fast[i] = rho(x[i]) = 1 / (1 + exp(x[i])) as the kernels evaluate it, out_ref[i] = the same through `/` and the literal e_exp.
+ * den != NULL: out_fast[i] = x[i] / den[i] through the reciprocal form, out_ref[i] = x[i] / den[i].  Both pairs must be equal bit for bit. */
+int rl_debug_rho(const double *x, const double *den, int32_t n, double *out_fast, double *out_ref);
 /* The exact parallel evaluation of Java float running sums (`float s = 0; for (k) s += x[k];`, learning/tree/LambdaMART.java:401-408,
  * :474-483) on arbitrary data: n doubles cut into n_seg segments (seg_start[0] = 0 ... seg_start[n_seg] = n), out[s] = the float
  * sum of segment s.  stats (may be null): int32[4] = segments evaluated, window misses repaired, segments finished serially, 0. */

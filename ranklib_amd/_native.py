@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "rl_set_train", "rl_set_validation", "rl_set_rows", "rl_set_external_judgments", "rl_init", "rl_boost_round", "rl_boost_rounds_async", "rl_sync",
     "rl_finish", "rl_num_trees", "rl_get_tree", "rl_get_round_metrics", "rl_best_validation", "rl_predict",
     "rl_model_to_text", "rl_model_from_text", "rl_model_destroy", "rl_model_num_trees", "rl_model_features",
-    "rl_model_predict", "rl_model_predict_device", "rl_dist_unique_id", "rl_dist_init", "rl_dist_init_callback", "rl_dist_stats", "rl_bin_stride", "rl_hist_features", "rl_quant_exponent", "rl_get_array", "rl_debug_exp", "rl_debug_float_chain",
+    "rl_model_predict", "rl_model_predict_device", "rl_dist_unique_id", "rl_dist_init", "rl_dist_init_callback", "rl_dist_stats", "rl_bin_stride", "rl_hist_features", "rl_quant_exponent", "rl_get_array", "rl_debug_exp", "rl_debug_rho", "rl_debug_float_chain",
     "rl_letor_parse", "rl_letor_info", "rl_letor_arrays", "rl_letor_rows", "rl_letor_destroy",
     "rl_get_timing", "rl_reset_timing", "rl_set_timing_flags", "rl_debug_membench", "rl_set_err_max", "rl_tree_capacity",
 ]
@@ -110,6 +110,7 @@ def lib():
     L.rl_quant_exponent.argtypes = [vp, C.POINTER(i32)]
     L.rl_get_array.argtypes = [vp, i32, vp, i64]
     L.rl_debug_exp.argtypes = [vp, i32, vp, vp]
+    L.rl_debug_rho.argtypes = [vp, vp, i32, vp, vp]
     L.rl_debug_float_chain.argtypes = [i32, vp, i64, vp, i32, vp, vp]
     L.rl_letor_parse.argtypes = [vp, i64, C.POINTER(vp)]
     L.rl_letor_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64)]
@@ -169,6 +170,17 @@ def debug_exp(x):
     x = np.ascontiguousarray(x, np.float64)
     a, b = np.zeros_like(x), np.zeros_like(x)
     check(lib().rl_debug_exp(x.ctypes.data, len(x), a.ctypes.data, b.ctypes.data))
+    return a, b
+
+
+def debug_rho(x, den=None):
+    """rl_debug_rho: (fast, ref) of rho(x) = 1 / (1 + exp(x)), or of x / den when den is given"""
+    x = np.ascontiguousarray(x, np.float64)
+    if den is not None:
+        den = np.ascontiguousarray(den, np.float64)
+        assert den.shape == x.shape
+    a, b = np.zeros_like(x), np.zeros_like(x)
+    check(lib().rl_debug_rho(x.ctypes.data, den.ctypes.data if den is not None else None, len(x), a.ctypes.data, b.ctypes.data))
     return a, b
 
 

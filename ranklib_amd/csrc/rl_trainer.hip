@@ -943,7 +943,12 @@ static int enqueue_round(rl_trainer *t)
                   t->tr.d_aux_i, t->tr.d_aux_a, t->tr.d_aux_b, t->d_wmax, t->tr.d_ext_rd};
         if (t->d_T == nullptr) {
             const int mode = (c.metric == RL_METRIC_ERR) ? 1 : (c.metric == RL_METRIC_MAP) ? 2 : 0;
-            auto lds_of = [&](int bt) { return (size_t)c.k * (bt + 8) * 16 + (size_t)c.k * 24 + lambda_fused_extra_bytes(mode, c.k, bt); };
+            // RLHIP_LAMBDA_COMPACT=1: NDCG / DCG pair terms from per-wavefront lists of the active pairs (k_lambda_fused<., 0, true>) instead of column by row.
+            // Built and measured slower at NDCG@10 (profiles/r05i_ab_lambda_c2.txt: a wavefront's ~390 active pairs are 3.05 steps of 128, i.e. 4 against the 5 of
+            // ten rows in pairs, and the lists cost LDS, registers and six ds_bpermute per pair); it is the shorter way from about NDCG@16 on.  Off by default.
+            static const bool cp_env = getenv("RLHIP_LAMBDA_COMPACT") && atoi(getenv("RLHIP_LAMBDA_COMPACT")) != 0;
+            const bool cp = cp_env && mode == 0;
+            auto lds_of = [&](int bt) { return (size_t)c.k * (bt + 8) * 16 + (size_t)c.k * 24 + lambda_fused_extra_bytes(mode, c.k, bt) + (cp ? lambda_fused_cp_bytes(c.k, bt) : 0); };
             n_max = 0;
             const DataSet &d = t->tr;
             // (ls: the stream of this class -- the main one, or one of the three side streams forked below)
@@ -959,7 +964,8 @@ static int enqueue_round(rl_trainer *t)
 #define RL_LAUNCH_FUSED(BT, cls)                                                                                                             \
             if (d.n_qcls[cls] > 0) {                                                                                                         \
                 hipStream_t ls = lam_stream();                                                                                               \
-                if (mode == 0) hipLaunchKernelGGL((k_lambda_fused<BT, 0>), dim3(d.n_qcls[cls]), dim3(BT), lds_of(BT), ls, g, (const int *)d.d_qcls[cls], d.n_qcls[cls]); \
+                if (cp) hipLaunchKernelGGL((k_lambda_fused<BT, 0, true>), dim3(d.n_qcls[cls]), dim3(BT), lds_of(BT), ls, g, (const int *)d.d_qcls[cls], d.n_qcls[cls]); \
+                else if (mode == 0) hipLaunchKernelGGL((k_lambda_fused<BT, 0>), dim3(d.n_qcls[cls]), dim3(BT), lds_of(BT), ls, g, (const int *)d.d_qcls[cls], d.n_qcls[cls]); \
                 else if (mode == 1) hipLaunchKernelGGL((k_lambda_fused<BT, 1>), dim3(d.n_qcls[cls]), dim3(BT), lds_of(BT), ls, g, (const int *)d.d_qcls[cls], d.n_qcls[cls]); \
                 else hipLaunchKernelGGL((k_lambda_fused<BT, 2>), dim3(d.n_qcls[cls]), dim3(BT), lds_of(BT), ls, g, (const int *)d.d_qcls[cls], d.n_qcls[cls]); \
                 n_max += d.n_qcls[cls]; g.blockmax = t->d_wmax + n_max;                                                                      \
@@ -1508,6 +1514,7 @@ int rl_create(const rl_params *p, rl_trainer **out)
     RL_HIP(hipFuncSetAttribute((const void *)k_rank_mixed, hipFuncAttributeMaxDynamicSharedMemorySize, std::max((kLambdaBlockCap + 63) & ~63, (kRankBlockThreads / 64) * kLambdaWaveCap) * kRankLdsPerDoc));
     RL_HIP(hipFuncSetAttribute((const void *)k_lambda_tiny, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaTinyGroups * lambda_tiny_group_bytes(kLambdaFusedMaxK)));
     RL_HIP(hipFuncSetAttribute((const void *)k_lambda_fused<256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaFusedMaxK * (256 + 8) * 16 + 2048));
+    RL_HIP(hipFuncSetAttribute((const void *)k_lambda_fused<256, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaFusedMaxK * (256 + 8) * 16 + 2048 + lambda_fused_cp_bytes(kLambdaFusedMaxK, 256)));
     RL_HIP(hipFuncSetAttribute((const void *)k_lambda_fused<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaFusedMaxK * (256 + 8) * 16 + 8192));
     RL_HIP(hipFuncSetAttribute((const void *)k_lambda_fused<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLambdaFusedMaxK * (256 + 8) * 16 + 8192));
     RL_HIP(hipFuncSetAttribute((const void *)k_chain_stitch, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2694,6 +2701,26 @@ int rl_debug_exp(const double *x, int32_t n, double *out_fast, double *out_ref)
     RL_HIP(hipMalloc((void **)&d, (size_t)n * 3 * sizeof(double)));
     RL_HIP(hipMemcpy(d, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_exp_probe, dim3((n + 255) / 256), dim3(256), 0, 0, (const double *)d, n, d + n, d + 2 * (size_t)n);
+    RL_HIP(hipGetLastError());
+    RL_HIP(hipDeviceSynchronize());
+    RL_HIP(hipMemcpy(out_fast, d + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    RL_HIP(hipMemcpy(out_ref, d + 2 * (size_t)n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return RL_OK;
+}
+
+int rl_debug_rho(const double *x, const double *den, int32_t n, double *out_fast, double *out_ref)
+{
+    if (!x || !out_fast || !out_ref || n < 0) return fail(RL_ERR_INVALID, "bad argument");
+    if (n == 0) return RL_OK;
+    double *d = nullptr;
+    RL_HIP(hipMalloc((void **)&d, (size_t)n * 4 * sizeof(double)));
+    RL_HIP(hipMemcpy(d, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    if (den) {
+        RL_HIP(hipMemcpy(d + 3 * (size_t)n, den, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_div_probe, dim3((n + 255) / 256), dim3(256), 0, 0, (const double *)d, (const double *)(d + 3 * (size_t)n), n, d + n, d + 2 * (size_t)n);
+    } else
+        hipLaunchKernelGGL(k_rho_probe, dim3((n + 255) / 256), dim3(256), 0, 0, (const double *)d, n, d + n, d + 2 * (size_t)n);
     RL_HIP(hipGetLastError());
     RL_HIP(hipDeviceSynchronize());
     RL_HIP(hipMemcpy(out_fast, d + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));

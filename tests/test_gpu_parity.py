@@ -591,6 +591,53 @@ def test_device_exp_equals_fdlibm_restatement_everywhere():
         assert same.all(), xs[~same][:5]
 
 
+def test_reciprocal_form_divisions_equal_the_ieee_quotient_bit_for_bit():
+    """rl_device.h div_by_rcp / rcp_newton2 / rho_fdlibm: the lambda kernels' divisions without the scaling steps == the compiler's IEEE division
+    (and == the oracle's 1 / (1 + StrictMath.exp) on the host), bit for bit, on the operand ranges the kernels use them on
+    (learning/tree/LambdaMART.java:383, metric/NDCGScorer.java:154) and on their edges"""
+    import ctypes as C
+    rng = np.random.RandomState(17)
+    # rho: every argument class of e_exp, the |x| >= 700 hand-over, infinities, NaN
+    edges = [0.0, -0.0, 2.0 ** -28, 2.0 ** -29, 0.34657359027997264, 1.0397207708399179, 699.9, 700.0, 700.1, 709.782712893384, 709.7827128933841,
+             -745.1332191019411, -745.2, -708.3, 710.0, 36.0, 36.8, 37.5, 1e-300, 88.0, 0.6931471805599453, 1.3862943611198906]
+    xs = []
+    for e in edges:
+        xs += [e, -e] if e == 0 else [np.nextafter(e, -np.inf), e, np.nextafter(e, np.inf), -np.nextafter(e, -np.inf), -e, -np.nextafter(e, np.inf)]
+    xs += [np.inf, -np.inf, np.nan]
+    xs = np.concatenate([np.array(xs), rng.uniform(-40, 40, 400000), rng.uniform(-760, 760, 100000), rng.uniform(-2, 2, 400000),
+                         rng.uniform(-1e-7, 1e-7, 20000), rng.standard_normal(400000) * 3, np.arange(-699, 700) * np.log(2.0)])
+    fast, ref = N.debug_rho(xs)
+    same = (fast.view(np.uint64) == ref.view(np.uint64)) | (np.isnan(fast) & np.isnan(ref))
+    assert same.all(), xs[~same][:5]
+    L = O.lib()
+    sub = np.concatenate([xs[:200], xs[-3000::7]])
+    f_sub = np.concatenate([fast[:200], fast[-3000::7]])
+    with np.errstate(over="ignore", invalid="ignore"):
+        want = np.array([1.0 / (1.0 + L.ro_exp(C.c_double(v))) for v in sub])
+    same = (f_sub.view(np.uint64) == want.view(np.uint64)) | (np.isnan(f_sub) & np.isnan(want))
+    assert same.all(), sub[~same][:5]
+    # quotients: numerators 0 or 2^-60 .. 2^70 of either sign, divisors 2^-200 .. 2^200 (lambda_div_fast), and e_exp's (x c) / +-(2 - c) shape
+    n = 1500000
+    num = np.ldexp(rng.uniform(1, 2, n), rng.randint(-60, 71, n)) * rng.choice([-1.0, 1.0], n)
+    den = np.ldexp(rng.uniform(1, 2, n), rng.randint(-200, 201, n))
+    num[:1000] = 0.0
+    den[1000:3000] = np.ldexp(1.0, rng.randint(-200, 201, 2000))                           # exact powers of two
+    den[3000:5000] = np.nextafter(np.ldexp(1.0, rng.randint(-199, 201, 2000)), 0)          # all-ones significands
+    num2 = rng.uniform(-0.13, 0.13, n) * np.ldexp(1.0, -rng.randint(0, 50, n))
+    den2 = rng.uniform(1.6, 2.4, n) * rng.choice([-1.0, 1.0], n)
+    # the discount / gain shapes themselves: (1/log2(i+2) - 1/log2(j+2)) (2^a - 2^b) over sums of gain * discount
+    i, j = rng.randint(0, 10, n), rng.randint(0, 3000, n)
+    disc = lambda p: 1.0 / (np.log(p + 2.0) / np.log(2.0))
+    num3 = (disc(i) - disc(j)) * (np.ldexp(1.0, rng.randint(0, 6, n)) - np.ldexp(1.0, rng.randint(0, 6, n)))
+    den3 = rng.uniform(0.3, 60.0, n)
+    for a, b in ((num, den), (num2, den2), (num3, den3)):
+        fast, ref = N.debug_rho(a, b)
+        nz = a != 0                                      # a zero numerator may give the other zero (rl_device.h): equal as values
+        assert (fast[nz].view(np.uint64) == ref[nz].view(np.uint64)).all()
+        assert (fast[~nz] == 0).all() and (ref[~nz] == 0).all()
+        assert (ref.view(np.uint64) == (a / b).view(np.uint64))[nz].all()
+
+
 # ---- edge cases: ragged / degenerate inputs, every way a tree can stop growing -----------------------------------------
 def _edge_cases():
     rng = np.random.RandomState(11)

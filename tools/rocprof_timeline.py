@@ -20,12 +20,14 @@ def main():
             return
         i0 = starts[-1]
     else:       # a round starts with its lambda kernels (whichever variants the data set uses) and k_max_reduce, then k_quantize
-        qs = [i for i, r in enumerate(rows) if "k_quantize" in r[0]]
+        qs = [i for i, r in enumerate(rows) if "k_max_reduce" in r[0] or "k_quantize" in r[0]]      # (the fused root pass has no k_quantize launch)
         if not qs:
-            print("no k_quantize launch in the trace")
+            print("no k_max_reduce / k_quantize launch in the trace")
             return
         i0 = qs[-1]
-        while i0 > 0 and any(x in rows[i0 - 1][0] for x in ("k_lambda_", "k_max_reduce", "k_pair_terms", "k_mart_residual")):
+        if "k_quantize" in rows[i0][0] and i0 > 0 and "k_max_reduce" in rows[i0 - 1][0]:
+            i0 -= 1
+        while i0 > 0 and any(x in rows[i0 - 1][0] for x in ("k_lambda_", "k_pair_terms", "k_mart_residual")):
             i0 -= 1
     t0 = rows[i0][1]
     prev_end = t0
