@@ -956,7 +956,8 @@ static int enqueue_round(rl_trainer *t)
             const bool fork = t->lam_streams && !t->dist;
             if (fork) { RL_HIP(hipEventRecord(t->ev_lam_fork, s)); }
             auto lam_stream = [&]() -> hipStream_t {
-                if (!fork || lam_used >= 3) return s;
+                static const int lam_side = getenv("RLHIP_LAMBDA_SIDE") ? std::max(0, std::min(3, atoi(getenv("RLHIP_LAMBDA_SIDE")))) : 3;      // side streams used (the rest of the classes: the main stream)
+                if (!fork || lam_used >= lam_side) return s;
                 hipStream_t ls = t->lam_s[lam_used++];
                 (void)hipStreamWaitEvent(ls, t->ev_lam_fork, 0);
                 return ls;
