@@ -110,7 +110,8 @@ def lib():
     L.rl_quant_exponent.argtypes = [vp, C.POINTER(i32)]
     L.rl_get_array.argtypes = [vp, i32, vp, i64]
     L.rl_debug_exp.argtypes = [vp, i32, vp, vp]
-    L.rl_debug_rho.argtypes = [vp, vp, i32, vp, vp]
+    if hasattr(L, "rl_debug_rho"):      # (A/B builds of older sources selected with RLHIP_LIB lack the probe; tests/test_abi.py checks the in-tree library's exports)
+        L.rl_debug_rho.argtypes = [vp, vp, i32, vp, vp]
     L.rl_debug_float_chain.argtypes = [i32, vp, i64, vp, i32, vp, vp]
     L.rl_letor_parse.argtypes = [vp, i64, C.POINTER(vp)]
     L.rl_letor_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64)]
