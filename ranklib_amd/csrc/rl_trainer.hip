@@ -110,6 +110,7 @@ struct rl_trainer {
     long long tie_stalls = 0, tie_nodes = 0, tie_chain_nodes = 0, tie_chain_docs = 0;      // lazy tie-break (rl_tie.inc): resolutions run, nodes resolved, chain nodes / documents summed
     long long tie_batches = 0;      // of the resolutions, the batched ones at the end of a tree (deferred ties)
     bool fin_split = false;      // wide data: k_hist_finish_wide + k_select instead of the fused finish (rl_init)
+    bool sel2_wide = true;       // k_select2<true> on data with 161 .. 768 histogram features (RLHIP_SELECT2_WIDE=0: k_select)
     bool step2 = true;           // k_fin2 (+ k_select2) instead of the fused finish / bookkeeping kernel (rl_step2.inc; RLHIP_STEP2=0: the round-4 kernels)
     long long tie_phase_us[6] = {0, 0, 0, 0, 0, 0};   // RLHIP_TIE_PROF: host microseconds per phase of resolve_ties (printed by rl_destroy)
     long long chain_calls[2] = {0, 0}, chain_repairs[2] = {0, 0}, chain_timeouts = 0, chain_wait_us = 0;      // RLHIP_CHAIN_PROF: float-chain evaluations [hinted, blind], repair passes enqueued, progress-word time-outs, host microseconds spent waiting for a stitch
@@ -1183,7 +1184,9 @@ static int enqueue_round(rl_trainer *t)
             hipLaunchKernelGGL(k_fin2, dim3(c.n_live, kSpec), dim3(kFin2Threads), 0, s, c);
             const size_t sel2_lds = select2_lds_bytes(c.L, c.NC);
             if (!c.fs_on && c.F <= kSel2MaxF && c.L > 0 && c.L + 2 <= 64 && sel2_lds <= 60 * 1024)
-                hipLaunchKernelGGL(k_select2, dim3(1), dim3(kSel2Threads), sel2_lds, s, c);
+                hipLaunchKernelGGL(k_select2<false>, dim3(1), dim3(kSel2Threads), sel2_lds, s, c);
+            else if (t->sel2_wide && !c.fs_on && c.F <= 32 * kWideS && c.L > 0 && c.L + 2 <= 64 && sel2_lds <= 60 * 1024)
+                hipLaunchKernelGGL(k_select2<true>, dim3(1), dim3(kSel2Threads), sel2_lds, s, c);       // (hundreds of features: the Yahoo-set1 shape)
             else hipLaunchKernelGGL(k_select, dim3(1), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
         } else if (t->fin_split || !nodes_in_lds) {       // (wide data; or node records that do not fit the LDS: the fused kernel has no path for them)
             hipLaunchKernelGGL(k_hist_finish_wide, dim3(c.n_live, kSpec), dim3(kFinWideThreads), (size_t)c.TS * 20 + 8 + par_lds, s, c);
@@ -1667,6 +1670,7 @@ int rl_init(rl_trainer *t)
     c.skip_last = 1;
     if (const char *e = getenv("RLHIP_SKIP_LAST")) c.skip_last = atoi(e) != 0;
     t->step2 = !(getenv("RLHIP_STEP2") && atoi(getenv("RLHIP_STEP2")) == 0);
+    t->sel2_wide = !(getenv("RLHIP_SELECT2_WIDE") && atoi(getenv("RLHIP_SELECT2_WIDE")) == 0);
     if (const char *e = getenv("RLHIP_BALANCE_CAP")) c.balance_cap = std::min(kChunk, std::max(1024, atoi(e) & ~255));
     if (const char *e = getenv("RLHIP_BALANCE_TARGET")) c.balance_target = std::max(8, atoi(e) & ~7);
     if (const char *e = getenv("RLHIP_BALANCE_MIN")) c.balance_min = std::max(1, atoi(e));

@@ -1115,6 +1115,31 @@ def test_wide_and_deep_shapes_match_the_oracle(F, n, leaves):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("wide", ["1", "0"])
+def test_bookkeeping_kernel_of_wide_data_gives_the_oracles_trees(wide, monkeypatch):
+    """161 .. 768 histogram features (the Yahoo-set1 shape): k_select2<true> (rl_step2.inc: the gains of a lane's share in registers, its best record and
+    the tie pass from memory, DPP reductions; RLHIP_SELECT2_WIDE=1, the default) or round 4's k_select -- against the oracle, stored (feature,
+    threshold) pairs included, on data with duplicated and mirrored columns spread over the lanes' shares (exact ties and mirrored cuts of OTHER
+    features: the stalled / deferred tie-break re-enters the bookkeeping), with a validation set"""
+    monkeypatch.setenv("RLHIP_SELECT2_WIDE", wide)
+    X, lab, qoff = make(5000, 400, "mslr", 91)
+    X[:, 37] = X[:, 5]; X[:, 170] = X[:, 5]; X[:, 399] = X[:, 5]         # the same column in three other shares
+    X[:, 222] = -X[:, 9]; X[:, 310] = X[:, 64] * 2.0                        # a mirrored cut, a rescaled copy
+    Xv, lv, qv = make(1500, 400, "mslr", 92)
+    Xv[:, 37] = Xv[:, 5]; Xv[:, 170] = Xv[:, 5]; Xv[:, 399] = Xv[:, 5]; Xv[:, 222] = -Xv[:, 9]; Xv[:, 310] = Xv[:, 64] * 2.0
+    o, g = pair(X, lab, qoff, n_trees=5, n_leaves=20)
+    o.set_validation(Xv, lv, qv); g.set_validation(Xv, lv, qv)
+    o.init(); g.init()
+    for r in range(5):
+        to, tmo, vmo, _ = o.round()
+        tg, tmg, vmg, _ = g.boost_round()
+        assert_same_tree(to, tg, X, "round %d" % r)
+        assert np.float32(tmo).view(np.uint32) == np.float32(tmg).view(np.uint32)
+        assert np.float32(vmo).view(np.uint32) == np.float32(vmg).view(np.uint32)
+        assert np.array_equal(g.array("SCORE").view(np.int64), o.scores().view(np.int64)), r
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("step2,split,extras", [("1", "0", "1"), ("1", "0", "0"), ("0", "0", "0"), ("0", "1", "0")])
 def test_fused_and_two_launch_finish_give_the_same_trees(step2, split, extras, monkeypatch):
     """The second half of a growth step: round 5's two short launches k_fin2 + k_select2 (rl_step2.inc; RLHIP_STEP2=1, the default) or round 4's kernels --
