@@ -994,7 +994,7 @@ static int enqueue_round(rl_trainer *t)
             n_max = (int)nb;
         }
     }
-    hipLaunchKernelGGL(k_max_reduce, dim3(1), dim3(1024), 0, s, (const double *)t->d_wmax, n_max, &c.st->maxabs_bits);
+    hipLaunchKernelGGL(k_max_reduce, dim3((unsigned)std::max(1, std::min(16, (n_max + 4095) / 4096))), dim3(1024), 0, s, (const double *)t->d_wmax, n_max, &c.st->maxabs_bits);
     if (t->dist) { int rcd = t->dist->allreduce(&c.st->maxabs_bits, 1, DT_U64, OP_MAX, s); if (rcd) return rcd; }
     // The plain one-GPU root pass makes the fixed-point lambdas itself (k_hist<.., FQ>): one pass over the documents and one launch less a round.
     // Sharded, strict-order and sparse-column runs (their kernels between here and the root pass read q) and a regrown tree (q exists) keep k_quantize.
