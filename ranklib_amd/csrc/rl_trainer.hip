@@ -957,7 +957,9 @@ static int enqueue_round(rl_trainer *t)
             const bool fork = t->lam_streams && !t->dist;
             if (fork) { RL_HIP(hipEventRecord(t->ev_lam_fork, s)); }
             auto lam_stream = [&]() -> hipStream_t {
-                static const int lam_side = getenv("RLHIP_LAMBDA_SIDE") ? std::max(0, std::min(3, atoi(getenv("RLHIP_LAMBDA_SIDE")))) : 3;      // side streams used (the rest of the classes: the main stream)
+                static const int lam_side = getenv("RLHIP_LAMBDA_SIDE") ? std::max(0, std::min(3, atoi(getenv("RLHIP_LAMBDA_SIDE")))) : 1;      // side streams used (the rest of the classes: the main stream).  One: the widest class beside the
+                // three others in a row on the main stream -- c2 423.1 -> 426.5 rounds/s against three side streams, c1 / c3 / c1ns within their noise
+                // (profiles/r05q_ab_lambda_side_*): the classes fill the chip either way, and a kernel that ends on a side stream is a cross-stream wait
                 if (!fork || lam_used >= lam_side) return s;
                 hipStream_t ls = t->lam_s[lam_used++];
                 (void)hipStreamWaitEvent(ls, t->ev_lam_fork, 0);
