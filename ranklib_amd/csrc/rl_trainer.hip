@@ -2930,7 +2930,13 @@ __global__ __launch_bounds__(kThreads) void k_model_eval(const EnsTree e, const 
 //   * the next tile of trees is fetched into registers while the current one is walked.
 // Needs: column offsets and child offsets that fit 16 bits, and the LDS budget; otherwise k_model_eval runs.
 // ------------------------------------------------------------------------------------------------
-constexpr int kEvalDocs = 64, kEvalParts = 4, kEvalPer = 8, kEvalTreeTile = kEvalParts * kEvalPer;
+#ifndef RL_EVAL_PARTS
+#define RL_EVAL_PARTS 4
+#endif
+#ifndef RL_EVAL_PER
+#define RL_EVAL_PER 8
+#endif
+constexpr int kEvalDocs = 64, kEvalParts = RL_EVAL_PARTS, kEvalPer = RL_EVAL_PER, kEvalTreeTile = kEvalParts * kEvalPer;
 constexpr int kEvalThreads = kEvalDocs * (kEvalParts + 1), kEvalPrefetch = 8;     // 8-byte words each thread prefetches per tile
 
 static inline size_t eval_tiled_lds(int cols, int maxn)
