@@ -264,11 +264,11 @@ def scaling_model(docs_per_rank, world, steps_tree=10.8, ar_bytes=None):
     share = docs_per_rank / 3.77e6
     if ar_bytes is None:
         ar_bytes = 2.2 * 559e3          # ~2.2 slots of 559 KB per step on average at F = 136
-    t_doc = (0.42 + 0.13 + 0.30 + 0.015) * share                   # lambdas, ranking, root pass + finish, score update
+    t_doc = (0.37 + 0.13 + 0.30 + 0.015) * share                   # lambdas, ranking, root pass + finish, score update (profiles/r05r_c2_kernel_stats.txt)
     t_step = steps_tree * (0.075 + 0.048 * share + 0.020 + ar_bytes / 40e9 * 1e3)
     # leaf sums: a leaf's float chain is one sequence with one owner rank; the largest leaf holds ~60 % of ALL documents early in training, so its owner
     # evaluates 0.6 x (documents of the whole job) whatever the rank count; + the exchange and its host hand-over when sharded
-    t_leaf = 0.27 * max(share, 0.6 * share * world) + (0.15 if world > 1 else 0.0)
+    t_leaf = 0.30 * max(share, 0.6 * share * world) + (0.15 if world > 1 else 0.0)
     return {"modelled_ms_per_round": t_doc + t_step + t_leaf, "modelled_rounds_per_s": 1000.0 / (t_doc + t_step + t_leaf), "world": world,
             "docs_per_rank": docs_per_rank, "growth_steps_per_tree": steps_tree, "allreduce_bytes_per_call": ar_bytes,
             "note": "modelled = per-document kernels x shard share + growth steps x (launch floor + shard's histogram work + one all-reduce) + leaf sums"}
