@@ -286,6 +286,7 @@ def main():
     ap.add_argument("--sustain", type=int, default=300, help="extra rounds after the timed region for config.sustained_rounds_per_s (0 = skip)")
     ap.add_argument("--node-rounds", type=int, default=10, help="extra rounds with HIP events around every child-node histogram launch (0 = skip)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes behind roofline.traffic")
+    ap.add_argument("--sharded-one-rank", action="store_true", help="N = 1 only: run the sharded (multi-GPU) code path on a one-rank RCCL communicator")
     ap.add_argument("--plain", action="store_true", help="timed region only: no CPU baseline, sustained run, node timing, membench or PMC passes")
     ap.add_argument("--metric", default="NDCG", help="train metric: NDCG (the BASELINE.json metric) | DCG | ERR | MAP (RankLib's own default is ERR@10)")
     ap.add_argument("--first-tie", action="store_true", help="RL_FLAG_FIRST_TIE: exact ties keep the first candidate (no lazy Java-order tie-break)")
@@ -360,6 +361,10 @@ def main():
             box = [g.dist_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             g.dist_init(box[0], rank, world)
+    elif args.sharded_one_rank:
+        # the SHARDED code path (partition from local counts, limb reduction, one all-reduce per growth step, leaf-owner exchange) on a one-rank
+        # RCCL communicator: prices everything of the N > 1 path but the wire, on the one GPU a builder's box has
+        g.dist_init(g.dist_unique_id(), 0, 1)
     g.init()
     t_init = time.time() - t0
 

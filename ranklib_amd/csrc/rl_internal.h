@@ -35,7 +35,6 @@ constexpr int kHistFG = 16;          // features per group of the histogram layo
 #define RL_PART_TILE 2048
 #endif
 constexpr int kPartTile = RL_PART_TILE;      // docs per partition tile (256 threads x 8)
-constexpr int kMemTileCap = 2048;    // round 6 (k_members): tiles of one growth step whose member counts a child-histogram block scans in LDS (N <= ~4.19 M documents; beyond: the in-line partition)
 constexpr int kMaxBins = 4096;       // bin stride limit (thresholds per feature incl. MAX_VALUE); 8 * bin must fit uint16
 constexpr int kHistLdsStride = 264;  // compile-time LDS row stride of the histogram kernels when TS <= 264 (the -tc 256 case: 257)
 constexpr int kHistLdsBytes = 64 * 1024;
@@ -99,20 +98,9 @@ struct TreeState {
     long long root_sq;                // sum over all docs of rint(lambda^2 * 2^E2)
     // lazy tie-break (rl_tie.inc): nodes select_step wanted to partition whose exactly tied best split the Java's rounding noise decides; while
     // stall_n > 0 the step has no slots (every growth kernel is a no-op) and the host runs the resolution kernels
-    int32_t stall_n, stall_node[kSpec], defer_any;      // defer_any: the tree holds nodes whose stored threshold awaits the batched tie-break
-    // round 6 (PartJob): partition jobs published in this tree (the root's is job 0); pj_resume: the bookkeeping is being resumed by k_tie_finish,
-    // whose slots REPLACE the pending (empty) job instead of following it
-    int32_t pj_seq, pj_resume, stall_pad[((4 - kSpec % 4) % 4) ? ((4 - kSpec % 4) % 4) : 4];
+    int32_t stall_n, stall_node[kSpec], defer_any, stall_pad[2 + (4 - kSpec % 4) % 4];      // defer_any: the tree holds nodes whose stored threshold awaits the batched tie-break
     SlotRec slot[kSpec];
     int32_t arrive1[kSpec][16];        // first-level arrival counters of k_hist_finish (<= 16 feature groups per slot)
-};
-
-// Round 6: the ordered (stable) partition of a growth step runs on a stream of its own BESIDE the step's member lists, child histograms, finish and
-// bookkeeping (k_members -> k_hist<.., ML> -> k_fin2 -> k_select2), so it reads its nodes from a copy the bookkeeping of the same step cannot
-// overwrite: job k & 1 of Ctx::pjob, k = jobs published in this tree before it (the host passes the parity of its own launch count).
-struct PartJob {
-    int32_t nslots, tiles_total, epoch, pad;
-    SlotRec slot[kSpec];
 };
 
 // one kept tree of the ensemble, nodes in creation order
@@ -180,10 +168,6 @@ struct Ctx {
     int32_t *idx[2];
     long long *ql[2];        // fixed-point lambda in sample-list order, valid for the ranges of BUILT children only (written by the partition
                              // that creates them; the lists themselves carry document ids alone)
-    // round 6, member lists (k_members): the BUILT child's documents of every partition tile, in list order, at the front of the tile's own 2 048-entry
-    // region (no offsets between tiles, hence no look-back): ids, fixed-point lambdas; tile_cnt holds the members per tile, tile_sq their lambda^2
-    int32_t *mem_idx; long long *mem_q;     // [nTiles * kPartTile]
-    PartJob *pjob;                          // [2] (null: the partition is launched in line and reads TreeState::slot)
     unsigned long long *tile_desc;   // [nTiles] look-back descriptors of the single-pass partition
     unsigned long long *tile_gdesc;  // [nTiles / 64 + kSpec + 1] totals of the groups of 64 tiles (lookback2_exclusive)
     NodeRec *nodes;

@@ -112,9 +112,6 @@ struct rl_trainer {
     bool fin_split = false;      // wide data: k_hist_finish_wide + k_select instead of the fused finish (rl_init)
     bool sel2_wide = true;       // k_select2<true> on data with 161 .. 768 histogram features (RLHIP_SELECT2_WIDE=0: k_select)
     bool step2 = true;           // k_fin2 (+ k_select2) instead of the fused finish / bookkeeping kernel (rl_step2.inc; RLHIP_STEP2=0: the round-4 kernels)
-    // round 6: the ordered partition beside the step (k_members -> k_hist<.., ML> -> k_fin2 -> k_select2 on the main stream, k_part_ids on part_s);
-    // RLHIP_STEP3=0: the partition in line, in front of the child histograms (round 5)
-    bool step3 = false; hipStream_t part_s = nullptr; hipEvent_t ev_sel[2] = {nullptr, nullptr}, ev_part[2] = {nullptr, nullptr};
     long long tie_phase_us[6] = {0, 0, 0, 0, 0, 0};   // RLHIP_TIE_PROF: host microseconds per phase of resolve_ties (printed by rl_destroy)
     long long chain_calls[2] = {0, 0}, chain_repairs[2] = {0, 0}, chain_timeouts = 0, chain_wait_us = 0;      // RLHIP_CHAIN_PROF: float-chain evaluations [hinted, blind], repair passes enqueued, progress-word time-outs, host microseconds spent waiting for a stitch
     long long tie_regrown = 0;      // trees grown a second time because a deferred tie over several features hid two different cuts (k_tie_verify)
@@ -462,14 +459,8 @@ static int launch_rank(rl_trainer *t, DataSet &d, const double *scores, double *
     return RL_OK;
 }
 
-// child passes from the per-tile member lists (round 6, k_members): the instantiations that exist
-static bool hist_ml_supported(const Ctx &c)
-{
-    return c.sub == 16 && c.TS <= kHistLdsStride && c.sub_child == 16 && c.hist_nt == kThreads && !(c.p8 > 1) && c.nTiles <= kMemTileCap && c.n_ranks == 1;
-}
-
 template <bool ROOT>
-static void launch_hist(const Ctx &c, int gx, int gy, size_t lds, hipStream_t s, bool fq = false, bool ml = false)
+static void launch_hist(const Ctx &c, int gx, int gy, size_t lds, hipStream_t s, bool fq = false)
 {
     // the XCD-aware block map of k_hist wants a multiple of 8 chunks (the extra blocks exit); child passes: a bounded grid whose blocks walk the
     // step's chunks (k_hist), about one resident set of blocks (3 per CU)
@@ -482,15 +473,6 @@ static void launch_hist(const Ctx &c, int gx, int gy, size_t lds, hipStream_t s,
     static const size_t lds_pad = getenv("RLHIP_HIST_LDSPAD") ? (size_t)atoi(getenv("RLHIP_HIST_LDSPAD")) : 0;
     if (!ROOT) lds += lds_pad;
     const dim3 g(gx, bounded(gx)), b(kThreads);
-    if constexpr (!ROOT) {
-        if (ml) {       // (hist_ml_supported)
-            const size_t lds_ml = lds + (size_t)(kMemTileCap + 1) * sizeof(int32_t);
-            if (c.crows && !c.any_runs) hipLaunchKernelGGL((k_hist<false, 16, kHistLdsStride, false, false, kThreads, true, false, true>), g, b, lds_ml, s, c);
-            else if (c.any_runs) hipLaunchKernelGGL((k_hist<false, 16, kHistLdsStride, true, false, kThreads, false, false, true>), g, b, lds_ml, s, c);
-            else hipLaunchKernelGGL((k_hist<false, 16, kHistLdsStride, false, false, kThreads, false, false, true>), g, b, lds_ml, s, c);
-            return;
-        }
-    }
     if (!ROOT && c.crows && c.sub == 16 && c.TS <= kHistLdsStride && !c.any_runs) {      // sparse data: compact rows (k_compact_rows)
         hipLaunchKernelGGL((k_hist<false, 16, kHistLdsStride, false, false, kThreads, true>), g, b, lds, s, c);
         return;
@@ -1061,15 +1043,6 @@ static int enqueue_round(rl_trainer *t)
         hipLaunchKernelGGL(k_fin2_root, dim3(c.n_live), dim3(kFin2RootThreads), 0, s, c, rootChunks);
         hipLaunchKernelGGL(k_select_root, dim3(1), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
     } else hipLaunchKernelGGL((k_hist_finish<true, false>), dim3(c.n_live), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
-    // round 6: the ordered partition of every growth step on part_s, beside the step (see k_members).  `bn`: partitions launched for this tree --
-    // partition k reads job k & 1, published by the bookkeeping launch before it (PartJob)
-    const bool use3 = t->step3 && c.pjob != nullptr && !t->dist && !c.java && t->step2 && c.TS <= kFin2MaxT && hist_ml_supported(c);
-    int bn = 0;
-    if (use3) RL_HIP(hipEventRecord(t->ev_sel[0], s));
-    const auto join_part = [&]() -> int {       // the main stream goes on once the last partition has ended (lists of the tree's nodes)
-        if (use3 && bn > 0 && !getenv("RLHIP_STEP3_INLINE")) RL_HIP(hipStreamWaitEvent(s, t->ev_part[(bn - 1) & 1], 0));
-        return RL_OK;
-    };
     // Growth steps: each prepares up to kSpec queue nodes and commits as many splits as the fit loop allows; L-1 steps
     // always suffice (every step commits at least the head of the queue); finished trees make the rest no-ops.
     const int steps = std::max(c.L - 1, 1);
@@ -1084,11 +1057,8 @@ static int enqueue_round(rl_trainer *t)
     int extra = 0, it = 0;
     bool saw_end = false;
     auto after_stall = [&](bool &ended) -> int {        // stream idle, tree stalled: resolve, then continue at the device's step
-        int rcj = join_part();
-        if (rcj) return rcj;
         int rcs = resolve_ties(t, fin_lds, nodes_in_lds);
         if (rcs) return rcs;
-        if (use3) RL_HIP(hipEventRecord(t->ev_sel[bn & 1], s));      // (k_tie_finish replaced the pending job: the next partition waits for it)
         extra += 2;
         if (c.progress) {       // resolve_ties waited for k_tie_finish, whose select_step left (step, done, deferred ties) in the pinned progress word
             const unsigned long long w = __atomic_load_n(t->h_progress, __ATOMIC_ACQUIRE);
@@ -1176,28 +1146,11 @@ static int enqueue_round(rl_trainer *t)
         if (t->dist) {      // local child sizes are unknown in advance: count pass, then scatter
             hipLaunchKernelGGL(k_part_count, dim3(c.nTiles), dim3(kThreads), 0, s, c);
             hipLaunchKernelGGL(k_part_scatter<false>, dim3(c.nTiles), dim3(kThreads), 0, s, c);
-        } else if (use3) {
-            static const int s3_inline = getenv("RLHIP_STEP3_INLINE") ? atoi(getenv("RLHIP_STEP3_INLINE")) : 0;      // measuring aid: 1 = the partition in line behind the member lists (no second stream), 2 = behind the child histograms
-            if (s3_inline) {
-                hipLaunchKernelGGL(k_members, dim3(c.nTiles), dim3(kThreads), 0, s, c);
-                if (s3_inline == 1) hipLaunchKernelGGL(k_part_ids, dim3(c.nTiles), dim3(kThreads), 0, s, c, bn & 1);
-                bn++;
-                { ScopedTiming tm(t, RL_KERNEL_HIST_NODE, 0.0); launch_hist<false>(c, hist_gx, c.maxChunks, hist_lds, s, false, true); }
-                if (s3_inline != 1) hipLaunchKernelGGL(k_part_ids, dim3(c.nTiles), dim3(kThreads), 0, s, c, (bn - 1) & 1);
-                goto hist_done;
-            }
-            RL_HIP(hipStreamWaitEvent(t->part_s, t->ev_sel[bn & 1], 0));          // the bookkeeping that published job bn
-            hipLaunchKernelGGL(k_part_ids, dim3(c.nTiles), dim3(kThreads), 0, t->part_s, c, bn & 1);
-            RL_HIP(hipEventRecord(t->ev_part[bn & 1], t->part_s));
-            if (bn > 0) RL_HIP(hipStreamWaitEvent(s, t->ev_part[(bn - 1) & 1], 0));    // this step's nodes got their lists from the previous partition
-            hipLaunchKernelGGL(k_members, dim3(c.nTiles), dim3(kThreads), 0, s, c);
-            bn++;
         } else hipLaunchKernelGGL(k_part_scatter<true>, dim3(c.nTiles), dim3(kThreads), 0, s, c);
         {
             ScopedTiming tm(t, RL_KERNEL_HIST_NODE, 0.0);
-            launch_hist<false>(c, hist_gx, c.maxChunks, hist_lds, s, false, use3);
+            launch_hist<false>(c, hist_gx, c.maxChunks, hist_lds, s);
         }
-      hist_done:
         if (t->dist) {
             hipLaunchKernelGGL(k_hist_reduce, dim3(c.F, kSpec), dim3(kFinThreads), red_lds, s, c, 0);
             // growth step `it` works on at most min(kSpec, 2^it) nodes (1 after the root, then at most twice the commits of the step
@@ -1237,13 +1190,11 @@ static int enqueue_round(rl_trainer *t)
             else if (t->sel2_wide && !c.fs_on && c.F <= 32 * kWideS && c.L > 0 && c.L + 2 <= 64 && sel2_lds <= 60 * 1024)
                 hipLaunchKernelGGL(k_select2<true>, dim3(1), dim3(kSel2Threads), sel2_lds, s, c);       // (hundreds of features: the Yahoo-set1 shape)
             else hipLaunchKernelGGL(k_select, dim3(1), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
-            if (use3) RL_HIP(hipEventRecord(t->ev_sel[bn & 1], s));
         } else if (t->fin_split || !nodes_in_lds) {       // (wide data; or node records that do not fit the LDS: the fused kernel has no path for them)
             hipLaunchKernelGGL(k_hist_finish_wide, dim3(c.n_live, kSpec), dim3(kFinWideThreads), (size_t)c.TS * 20 + 8 + par_lds, s, c);
             hipLaunchKernelGGL(k_select, dim3(1), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
         } else hipLaunchKernelGGL((k_hist_finish<false, false>), dim3(c.n_live, kSpec), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
     }
-    { int rcj = join_part(); if (rcj) return rcj; }
     if (c.tie_on && !saw_end) {
         // every step was enqueued without the host ever seeing the end of the tree (no progress word, a spin timeout, or a tree of fewer steps
         // than the host keeps in flight): a stall may have gone unnoticed -- look, once per round
@@ -1532,16 +1483,11 @@ int rl_create(const rl_params *p, rl_trainer **out)
     RL_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
     RL_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
     RL_HIP(hipEventCreateWithFlags(&t->ev_ranked, hipEventDisableTiming)); RL_HIP(hipEventCreateWithFlags(&t->ev_metric, hipEventDisableTiming));
-    RL_HIP(hipStreamCreateWithFlags(&t->part_s, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) { RL_HIP(hipEventCreateWithFlags(&t->ev_sel[i], hipEventDisableTiming)); RL_HIP(hipEventCreateWithFlags(&t->ev_part[i], hipEventDisableTiming)); }
     t->lam_streams = !(getenv("RLHIP_LAMBDA_STREAMS") && atoi(getenv("RLHIP_LAMBDA_STREAMS")) == 0);
     if (t->lam_streams) {
         RL_HIP(hipEventCreateWithFlags(&t->ev_lam_fork, hipEventDisableTiming));
         for (int i = 0; i < 3; i++) { RL_HIP(hipStreamCreateWithFlags(&t->lam_s[i], hipStreamNonBlocking)); RL_HIP(hipEventCreateWithFlags(&t->ev_lam_join[i], hipEventDisableTiming)); }
     }
-    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 16, kHistLdsStride, false, false, kThreads, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
-    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 16, kHistLdsStride, true, false, kThreads, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
-    RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 16, kHistLdsStride, false, false, kThreads, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 16, kHistLdsStride>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<false, 16, kHistLdsStride>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
     RL_HIP(hipFuncSetAttribute((const void *)k_hist<true, 16, kHistLdsStride, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kHistLdsBytes));
@@ -1595,8 +1541,6 @@ void rl_destroy(rl_trainer *t)
                 t->chain_calls[0], t->chain_repairs[0], t->chain_calls[1], t->chain_repairs[1], t->chain_timeouts, t->chain_wait_us);
     if (t->stream) { (void)hipStreamSynchronize(t->stream); }
     if (t->side) { (void)hipStreamSynchronize(t->side); (void)hipStreamDestroy(t->side); }
-    if (t->part_s) { (void)hipStreamSynchronize(t->part_s); (void)hipStreamDestroy(t->part_s); }
-    for (int i = 0; i < 2; i++) { if (t->ev_sel[i]) (void)hipEventDestroy(t->ev_sel[i]); if (t->ev_part[i]) (void)hipEventDestroy(t->ev_part[i]); }
     if (t->ev_lam_fork) (void)hipEventDestroy(t->ev_lam_fork);
     for (int i = 0; i < 3; i++) { if (t->ev_lam_join[i]) (void)hipEventDestroy(t->ev_lam_join[i]); if (t->lam_s[i]) (void)hipStreamDestroy(t->lam_s[i]); }
     if (t->ev_ranked) (void)hipEventDestroy(t->ev_ranked);
@@ -2287,13 +2231,6 @@ int rl_init(rl_trainer *t)
     RL_HIP(t->pool.alloc(&c.fb_root, (size_t)2 + kSpec)); c.fb_sq = c.fb_root + 2;
     RL_HIP(t->pool.alloc(&c.tile_cnt, (size_t)c.nTiles)); RL_HIP(t->pool.alloc(&c.tile_sq, (size_t)c.nTiles));
     RL_HIP(t->pool.alloc(&c.tile_desc, (size_t)c.nTiles)); RL_HIP(hipMemset(c.tile_desc, 0, (size_t)c.nTiles * 8));
-    // round 6: per-tile member lists of the built children + the partition jobs (k_members / k_part_ids); RLHIP_STEP3=0: the in-line partition
-    t->step3 = !(getenv("RLHIP_STEP3") && atoi(getenv("RLHIP_STEP3")) == 0) && !t->dist && !c.java && t->step2 && c.TS <= kFin2MaxT && c.nTiles <= kMemTileCap;
-    c.mem_idx = nullptr; c.mem_q = nullptr; c.pjob = nullptr;
-    if (t->step3) {
-        RL_HIP(t->pool.alloc(&c.mem_idx, (size_t)c.nTiles * kPartTile)); RL_HIP(t->pool.alloc(&c.mem_q, (size_t)c.nTiles * kPartTile));
-        RL_HIP(t->pool.alloc(&c.pjob, (size_t)2)); RL_HIP(hipMemset(c.pjob, 0, 2 * sizeof(PartJob)));
-    }
     RL_HIP(t->pool.alloc(&c.tile_gdesc, (size_t)c.nTiles / 64 + kSpec + 2)); RL_HIP(hipMemset(c.tile_gdesc, 0, ((size_t)c.nTiles / 64 + kSpec + 2) * 8));
     RL_HIP(t->pool.alloc(&c.grow_stats, (size_t)4)); RL_HIP(hipMemset(c.grow_stats, 0, 16));
     RL_HIP(t->pool.alloc(&c.grow_docs, (size_t)4)); RL_HIP(hipMemset(c.grow_docs, 0, 32));
