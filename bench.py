@@ -295,6 +295,8 @@ def main():
     ap.add_argument("--scaling", default="strong", help="strong (default: the SAME data set sharded over --gpus ranks, what BASELINE.json configs[2] states) | "
                                                        "weak (--gpus x the shape's documents: the same documents per rank at every N)")
     ap.add_argument("--c1-trees", type=int, default=1000, help="after the headline run: BASELINE.json configs[1] as stated (c1 shape, this many trees) -> config.c1_full_run (0 = skip; N = 1 only)")
+    ap.add_argument("--c2-trees", type=int, default=1000, help="after the headline run (c2, N = 1): the same shape as a whole run of this many trees -> config.c2_full_run (0 = skip)")
+    ap.add_argument("--shard1-rounds", type=int, default=40, help="after the headline run (c2, N = 1): the sharded code path on a one-rank RCCL communicator beside the plain path -> config.sharded_path_one_rank (0 = skip)")
     ap.add_argument("--ns-rounds", type=int, default=20, help="after the headline run (c2, N = 1): the north-star list-length variant of the same shape, c2ns "
                     "(~10 docs/query, 377 k queries), timed over this many rounds -> config.c2ns (0 = skip)")
     ap.add_argument("--trees", type=int, default=10000, help="infer: trees in the scored model")
@@ -302,7 +304,7 @@ def main():
     ap.add_argument("--infer-train-rounds", type=int, default=100)
     args = ap.parse_args()
     if args.plain:
-        args.cpu_rounds, args.sustain, args.node_rounds, args.no_pmc, args.no_timing, args.c1_trees, args.ns_rounds = 0, 0, 0, True, True, 0, 0
+        args.cpu_rounds, args.sustain, args.node_rounds, args.no_pmc, args.no_timing, args.c1_trees, args.ns_rounds, args.c2_trees, args.shard1_rounds = 0, 0, 0, True, True, 0, 0, 0, 0
     if args.workload == "infer":
         if not any(a.startswith("--steps") for a in sys.argv):
             args.steps, args.warmup = 3, 1
@@ -628,10 +630,52 @@ def main():
             "ndcg10_train_oracle": lp.get("ndcg10_train_oracle") if same_run else None, "ndcg10_heldout_oracle": lp.get("ndcg10_heldout_oracle") if same_run else None,
             "first_divergent_round": lp.get("first_divergent_round") if same_run else None, "rounds_compared_identical": lp.get("rounds_compared_identical") if same_run else None,
             "splits_compared": lp.get("splits_compared") if same_run else None, "splits_storing_another_candidate": lp.get("splits_storing_another_candidate") if same_run else None,
-            "oracle_source": "profiles/r05_long_parity_c1.json (tools/long_parity.py c1 1000: GPU and oracle side by side, every round compared)" if same_run else None,
+            "oracle_source": "CACHED figures: profiles/r05_long_parity_c1.json, logged by tools/long_parity.py c1 1000 at commit f0857ba (GPU and oracle side by side, every round compared); "
+                             "they describe this run only while ranklib_amd/synth.py generates the same data -- a non-zero |diff| below means the GPU side or the data changed, not that the oracle was re-run" if same_run else None,
             "heldout_abs_diff_vs_oracle": (abs(ho_g - lp["ndcg10_heldout_oracle"]) if same_run else None),
             "train_abs_diff_vs_oracle": (abs(tr_g - lp["ndcg10_train_oracle"]) if same_run else None)}
         del g1, Xh
+
+    if world == 1 and args.c2_trees > 0 and args.shape == "c2" and not args.java_order and not args.sharded_one_rank:
+        # BASELINE.json configs[2]'s shape as a WHOLE run on one GPU (the headline is a window of early trees; late trees take twice the growth steps)
+        g2 = N.Trainer(n_trees=args.c2_trees, n_leaves=n_leaves, device=local_rank)
+        g2.set_train(X, lab, qoff)
+        g2.init()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        g2.boost_rounds_async(args.c2_trees)
+        g2.sync()
+        dt2 = time.perf_counter() - t1
+        out["config"]["c2_full_run"] = {"workload": "%d docs x %d features, %d queries, %d trees x %d leaves, one GPU, the whole run" % (n_docs, n_feat, q_total, args.c2_trees, n_leaves),
+                                        "rounds_per_s": args.c2_trees / dt2, "seconds": dt2, "ndcg10_train": float(g2.round_metrics(args.c2_trees - 1)[0])}
+        del g2
+    if world == 1 and args.shard1_rounds > 0 and args.shape == "c2" and not args.java_order and not args.sharded_one_rank:
+        # the SHARDED code path (what every rank of an N > 1 job runs: partition from local counts, limb reduction, one all-reduce per growth step,
+        # leaf-owner exchange, gathered metric) on a one-rank RCCL communicator, beside the plain path on the same box: everything of the multi-GPU
+        # path but the wire.  The trees must be the plain path's (checked on the train metric of the last round).
+        def timed(sharded):
+            gs = N.Trainer(n_trees=5 + args.shard1_rounds, n_leaves=n_leaves, device=local_rank)
+            gs.set_train(X, lab, qoff)
+            if sharded:
+                gs.dist_init(gs.dist_unique_id(), 0, 1)
+            gs.init()
+            gs.boost_rounds_async(5); gs.sync()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            gs.boost_rounds_async(args.shard1_rounds); gs.sync()
+            dts = time.perf_counter() - t1
+            gst = gs.array("GROW_STATS")
+            return args.shard1_rounds / dts, float(gs.round_metrics(5 + args.shard1_rounds - 1)[0]), float(gst[0]) / max(int(gst[3]), 1)
+        try:
+            r_plain, m_plain, _ = timed(False)
+            r_shard, m_shard, st_shard = timed(True)
+            out["config"]["sharded_path_one_rank"] = {
+                "what": "the sharded code path on a one-rank RCCL communicator at this shape, %d rounds after 5, same box, same process" % args.shard1_rounds,
+                "sharded_path_one_rank_rounds_per_s": r_shard, "plain_path_rounds_per_s": r_plain, "ratio": r_shard / r_plain,
+                "growth_steps_per_tree": round(st_shard, 2), "same_train_metric_as_plain_path": bool(m_plain == m_shard)}
+            out["config"]["sharded_path_one_rank_rounds_per_s"] = r_shard
+        except Exception as ex:      # noqa: BLE001  (librccl missing on the box: the field says so instead of a number)
+            out["config"]["sharded_path_one_rank"] = {"error": repr(ex)[:300]}
 
     if world == 1 and args.ns_rounds > 0 and args.shape == "c2" and not args.java_order:
         # the north star's own list length ("~10 docs/query") at the same size: SURVEY.md 8d asks for both variants

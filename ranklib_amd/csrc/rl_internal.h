@@ -113,6 +113,7 @@ struct Ctx {
     int32_t N, Npad, Q, F, TS, L, MAXN, NC, mls, k, maxChunks, nTiles, FG, numFG;   // MAXN = 2L-1 tree nodes, NC = node records incl. speculation
     float lr;
     int32_t rank, n_ranks;
+    int32_t sharded;              // a communicator exists (rl_dist_init*), whatever its size: local sample ranges are not known in advance, histograms are all-reduced (rl_dist.inc)
     int32_t Nglobal;              // documents over ALL ranks (== N on one GPU): fixes the lambda^2 exponent, which every rank must share
     int32_t sub_child;            // features per block of the child-node histogram passes (16, or 8 / 4: RLHIP_SUB_CHILD)
     int32_t hist_nt;              // threads per block of the child-node histogram passes (256 / 512 / 1024; launch_hist)
@@ -174,6 +175,8 @@ struct Ctx {
     TreeState *st;
     int32_t *queue;
     long long *cum_hi; unsigned long long *cum_lo; int32_t *cum_cnt;   // [MAXN][F][TS] cumulative
+    int32_t *cum_cnt_loc;     // sharded runs (round 6): THIS rank's cumulative counts of every live node (k_hist_reduce) -- the local size of a node's left child is
+                              // cum_cnt_loc[node][best_f][best_t], so the single-pass partition and exact chunks need no count pass (null: unsharded)
     long long *part_sum; int32_t *part_cnt;                            // [maxChunks][F][TS]
     long long *part_tot;                                               // [maxChunks] sum of q over the chunk's samples
     struct FeatBest *fb;                                               // [kSpec][2][F] per-feature best split of each new node (rl_kernels_round.inc)

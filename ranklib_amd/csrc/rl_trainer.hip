@@ -91,6 +91,7 @@ struct rl_trainer {
     // the lambda kernels of the list-length classes are independent: three of them run on streams of their own beside the main one, so that the tail
     // of one class (its last blocks) overlaps the next class instead of idling the chip (RLHIP_LAMBDA_STREAMS=0: one after the other)
     hipStream_t lam_s[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev_lam_fork = nullptr, ev_lam_join[3] = {nullptr, nullptr, nullptr}; bool lam_streams = false;
+    int32_t lam_side = 1; bool lam_compact = false;      // RLHIP_LAMBDA_SIDE / RLHIP_LAMBDA_COMPACT, read when the trainer is created (they were process-wide statics)
     DevPool pool;
     Ctx ctx;
     EnsTree ens;
@@ -103,7 +104,7 @@ struct rl_trainer {
     // growth progress reported by the device (Ctx::progress): the host keeps at most `step_ahead` growth steps in flight and
     // stops enqueuing steps of a finished tree; 0 = enqueue all L-1 steps blindly
     unsigned long long *h_progress = nullptr; uint32_t tree_seq = 0; int32_t step_ahead = 1;       // (1: c2 409.5 -> 411.7 rounds/s against 3, profiles/r05g_ab_step_ahead_c2.txt -- fewer empty steps behind a finished tree)
-    int32_t dist_ahead = 0;     // sharded runs: growth steps enqueued beyond the last one whose bookkeeping the host has seen -- 0: every enqueued step has work (an empty
+    int32_t dist_ahead = 1;     // sharded runs: growth steps enqueued beyond the last one whose bookkeeping the host has seen -- 0: every enqueued step has work (an empty
                                 // step still costs its all-reduce on every rank); RLHIP_DIST_STEP_AHEAD
     unsigned long long chain_seq = 0; std::vector<void *> pinned;     // chain pass tags; pinned words of the chains (freed in rl_destroy)
     int32_t synced_rounds = 0;
@@ -144,6 +145,7 @@ struct rl_trainer {
     double *d_gx = nullptr, *d_send = nullptr; int32_t *d_gls = nullptr; int32_t lsstride = 0; float *d_gres = nullptr;     // leaf-owner exchange: receive / send buffers
     int32_t *d_own = nullptr; long long *d_xtab = nullptr;     // owner of every leaf; pack / assemble offsets (rl_dist.inc LeafExchange)
     std::vector<int32_t> h_gls, h_own; std::vector<long long> h_xtab;
+    long long *h_xmail = nullptr, *d_xmail = nullptr, xmail_tag = 0;     // pinned mailbox of k_plan_exchange (transfer sizes of the leaf-owner exchange): no stream synchronisation in a round
     double *d_qsend = nullptr, *d_qgath = nullptr, *d_qcat = nullptr; int32_t *d_allQ = nullptr;
     // the same for the validation set (sharded by query like the training set)
     int32_t vQglobal = 0, vQmax = 0; double *d_vqsend = nullptr, *d_vqgath = nullptr, *d_vqcat = nullptr; int32_t *d_vallQ = nullptr;
@@ -467,7 +469,7 @@ static void launch_hist(const Ctx &c, int gx, int gy, size_t lds, hipStream_t s,
     static const int grid_blocks = getenv("RLHIP_HIST_GRID") ? atoi(getenv("RLHIP_HIST_GRID")) : 1024;
     // (balanced steps -- balance_slots -- want exactly balance_target rows: block row r then works through the chunks r, r + balance_target, ..)
     static const bool grid_env = getenv("RLHIP_HIST_GRID") != nullptr;        // (cached: this runs thousands of times a second)
-    const auto bounded = [&](int gxx) { return ROOT ? ((gy + 7) & ~7) : (c.balance && c.n_ranks == 1 && !grid_env) ? std::min((gy + 7) & ~7, c.balance_target)
+    const auto bounded = [&](int gxx) { return ROOT ? ((gy + 7) & ~7) : (c.balance && (!c.sharded || c.cum_cnt_loc) && !grid_env) ? std::min((gy + 7) & ~7, c.balance_target)
                                                                       : std::min((gy + 7) & ~7, std::max(8, ((grid_blocks + gxx - 1) / gxx + 7) & ~7)); };
     // (RLHIP_HIST_LDSPAD: extra dynamic LDS per child-pass block -- 28 KB caps a CU at two blocks; a measuring aid)
     static const size_t lds_pad = getenv("RLHIP_HIST_LDSPAD") ? (size_t)atoi(getenv("RLHIP_HIST_LDSPAD")) : 0;
@@ -947,17 +949,16 @@ static int enqueue_round(rl_trainer *t)
             // RLHIP_LAMBDA_COMPACT=1: NDCG / DCG pair terms from per-wavefront lists of the active pairs (k_lambda_fused<., 0, true>) instead of column by row.
             // Built and measured slower at NDCG@10 (profiles/r05i_ab_lambda_c2.txt: a wavefront's ~390 active pairs are 3.05 steps of 128, i.e. 4 against the 5 of
             // ten rows in pairs, and the lists cost LDS, registers and six ds_bpermute per pair); it is the shorter way from about NDCG@16 on.  Off by default.
-            static const bool cp_env = getenv("RLHIP_LAMBDA_COMPACT") && atoi(getenv("RLHIP_LAMBDA_COMPACT")) != 0;
-            const bool cp = cp_env && mode == 0;
+            const bool cp = t->lam_compact && mode == 0;
             auto lds_of = [&](int bt) { return (size_t)c.k * (bt + 8) * 16 + (size_t)c.k * 24 + lambda_fused_extra_bytes(mode, c.k, bt) + (cp ? lambda_fused_cp_bytes(c.k, bt) : 0); };
             n_max = 0;
             const DataSet &d = t->tr;
             // (ls: the stream of this class -- the main one, or one of the three side streams forked below)
             int lam_used = 0;
-            const bool fork = t->lam_streams && !t->dist;
+            const bool fork = t->lam_streams;       // (sharded runs too, round 6: the classes only touch this rank's lists; the collectives follow on the main stream behind the join)
             if (fork) { RL_HIP(hipEventRecord(t->ev_lam_fork, s)); }
             auto lam_stream = [&]() -> hipStream_t {
-                static const int lam_side = getenv("RLHIP_LAMBDA_SIDE") ? std::max(0, std::min(3, atoi(getenv("RLHIP_LAMBDA_SIDE")))) : 1;      // side streams used (the rest of the classes: the main stream).  One: the widest class beside the
+                const int lam_side = t->lam_side;      // side streams used (the rest of the classes: the main stream).  One: the widest class beside the
                 // three others in a row on the main stream -- c2 423.1 -> 426.5 rounds/s against three side streams, c1 / c3 / c1ns within their noise
                 // (profiles/r05q_ab_lambda_side_*): the classes fill the chip either way, and a kernel that ends on a side stream is a cross-stream wait
                 if (!fork || lam_used >= lam_side) return s;
@@ -980,7 +981,11 @@ static int enqueue_round(rl_trainer *t)
                                    (size_t)kLambdaTinyGroups * lambda_tiny_group_bytes(c.k), s, g, (const int *)d.d_qcls[4], d.n_qcls[4]);
                 n_max += nb; g.blockmax = t->d_wmax + n_max;
             } else {
-                RL_LAUNCH_FUSED(64, 4)          // ERR / MAP: the lists of at most 16 documents take the block-per-query kernel too
+                // ERR / MAP: the lists of at most 16 documents take the block-per-query kernel too -- on the main stream: the side stream is for the
+                // widest class below (the first class launched used to take it)
+                const int keep = lam_used; lam_used = 1 << 20;
+                RL_LAUNCH_FUSED(64, 4)
+                lam_used = keep;
             }
             // longest lists first on the side streams (they take longest per block), the shortest class last on the main stream
             RL_LAUNCH_FUSED(256, 3)
@@ -1001,7 +1006,7 @@ static int enqueue_round(rl_trainer *t)
     // The plain one-GPU root pass makes the fixed-point lambdas itself (k_hist<.., FQ>): one pass over the documents and one launch less a round.
     // Sharded, strict-order and sparse-column runs (their kernels between here and the root pass read q) and a regrown tree (q exists) keep k_quantize.
     static const bool fq_env = !(getenv("RLHIP_FUSED_QUANT") && atoi(getenv("RLHIP_FUSED_QUANT")) == 0);
-    bool root_quant_fused = fq_env && !t->dist && !c.java && !c.sp_on && c.sub == 16 && c.TS <= kHistLdsStride && !c.any_runs;
+    bool root_quant_fused = fq_env && !c.java && !c.sp_on && c.sub == 16 && c.TS <= kHistLdsStride && !c.any_runs;       // (sharded runs too, round 6: max |lambda| is all-reduced before this point, nothing between here and the root pass reads q)
     if (!root_quant_fused) hipLaunchKernelGGL(k_quantize, dim3(std::min(2048, (c.N + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, c);
     const size_t hist_lds = (size_t)c.sub * ((c.sub == 16 && c.TS <= kHistLdsStride) ? kHistLdsStride : c.TS) * 12;    // int64 sums + int32 counts
     const int hist_gx = c.numFG * (kHistFG / c.sub);
@@ -1143,7 +1148,7 @@ static int enqueue_round(rl_trainer *t)
             if (!t->dist && stalled(w)) { it--; continue; }       // handled at the top of the loop
             if (!t->dist && finished(w)) { saw_end = true; defer_seen = ((w >> 30) & 1ull) != 0; break; }
         }
-        if (t->dist) {      // local child sizes are unknown in advance: count pass, then scatter
+        if (t->dist && !c.cum_cnt_loc) {      // local child sizes unknown in advance: count pass, then scatter (round 5; RLHIP_DIST_COUNT_PASS=1)
             hipLaunchKernelGGL(k_part_count, dim3(c.nTiles), dim3(kThreads), 0, s, c);
             hipLaunchKernelGGL(k_part_scatter<false>, dim3(c.nTiles), dim3(kThreads), 0, s, c);
         } else hipLaunchKernelGGL(k_part_scatter<true>, dim3(c.nTiles), dim3(kThreads), 0, s, c);
@@ -1158,7 +1163,13 @@ static int enqueue_round(rl_trainer *t)
             const int max_slots = std::min(kSpec, 1 << std::min(it, 8));
             int rcd = t->dist->allreduce(c.dist_buf, slot_words * max_slots, DT_I64, OP_SUM, s);
             if (rcd) return rcd;
-            hipLaunchKernelGGL((k_hist_finish<false, true>), dim3(c.F, kSpec), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
+            // round 6: the finish and the bookkeeping of the plain path's step (rl_step2.inc) on the all-reduced limbs; the round-4 fused kernel for what
+            // k_select2 does not cover (feature sampling, more than 160 features, more than 62 leaves)
+            const size_t sel2_lds_d = select2_lds_bytes(c.L, c.NC);
+            if (t->step2 && c.TS <= kFin2MaxT && !c.fs_on && c.F <= kSel2MaxF && c.L > 0 && c.L + 2 <= 64 && sel2_lds_d <= 60 * 1024) {
+                hipLaunchKernelGGL(k_fin2<true>, dim3(c.F, kSpec), dim3(kFin2Threads), 0, s, c);
+                hipLaunchKernelGGL(k_select2<false>, dim3(1), dim3(kSel2Threads), sel2_lds_d, s, c);
+            } else hipLaunchKernelGGL((k_hist_finish<false, true>), dim3(c.F, kSpec), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
             // Sharded runs pay a collective per step even when the tree is already finished, so the host looks at the
             // (rank-invariant) `done` flag now and then and stops enqueuing: a stream sync costs far less than the
             // all-reduces of ~20 empty steps.  One GPU keeps the fully asynchronous schedule (an empty step is 3 tiny launches).
@@ -1183,7 +1194,7 @@ static int enqueue_round(rl_trainer *t)
             hipLaunchKernelGGL((k_hist_finish<false, false, true>), dim3(c.n_live, kSpec), dim3(kFinThreads), fin_lds, s, c, nodes_in_lds);
         } else if (t->step2 && c.TS <= kFin2MaxT) {
             // rl_step2.inc: one bin per thread, DPP scans, plain stores -- then the bookkeeping as a launch of its own
-            hipLaunchKernelGGL(k_fin2, dim3(c.n_live, kSpec), dim3(kFin2Threads), 0, s, c);
+            hipLaunchKernelGGL(k_fin2<false>, dim3(c.n_live, kSpec), dim3(kFin2Threads), 0, s, c);
             const size_t sel2_lds = select2_lds_bytes(c.L, c.NC);
             if (!c.fs_on && c.F <= kSel2MaxF && c.L > 0 && c.L + 2 <= 64 && sel2_lds <= 60 * 1024)
                 hipLaunchKernelGGL(k_select2<false>, dim3(1), dim3(kSel2Threads), sel2_lds, s, c);
@@ -1210,60 +1221,80 @@ static int enqueue_round(rl_trainer *t)
     }
     // the score update streams over the documents when the leaf sums' gather can leave every document's leaf behind (one GPU, parallel chains, <= 1024 leaves)
     const bool stream_env = !(getenv("RLHIP_SCORE_STREAM") && atoi(getenv("RLHIP_SCORE_STREAM")) == 0);        // (read per round: a test switches it)
-    const bool stream_scores = stream_env && !t->dist && !(t->p.flags & RL_FLAG_SERIAL_CHAIN) && c.leaf_of != nullptr && c.L > 0 && c.L <= 1024;
+    const bool stream_scores = stream_env && !(t->p.flags & RL_FLAG_SERIAL_CHAIN) && c.leaf_of != nullptr && c.L > 0 && c.L <= 1024;       // (sharded runs too, round 6: the local gather in leaf order leaves every document's leaf behind)
     hipLaunchKernelGGL(k_leaf_table, dim3(1), dim3(kThreads), 0, s, c, t->leaf_chain, t->d_seg_buf);
     if (t->p.flags & RL_FLAG_SERIAL_CHAIN) {
         hipLaunchKernelGGL(k_leaf_chain, dim3(c.L), dim3(64), 0, s, c);
     } else if (t->dist) {
         // multi-GPU: gather lambda / weight in leaf order from every rank and evaluate the chains over the whole leaf
         // multi-GPU, the leaf-owner exchange (rl_dist.inc): lambda / weight of a leaf's documents go to the leaf's owner rank only
-        ChainSource src{nullptr, nullptr, c.lw, c.idx[0], c.idx[1], t->d_seg_buf};
+        ChainSource src{nullptr, nullptr, c.lw, c.idx[0], c.idx[1], t->d_seg_buf, stream_scores ? c.leaf_of : nullptr};
         const ChainBufs &lb = t->leaf_chain;
         const int R = t->n_ranks, me = t->dist->rank, nseg = std::max(c.L, 2), MS = t->gchain.maxseg;      // -leaf 1 still has two leaves (the root always splits)
         hipLaunchKernelGGL(k_chain_prefix, dim3((unsigned)((lb.cap_tiles + 3) / 4)), dim3(kThreads), 0, s, lb, src);      // local values in leaf order -> lb.xs
         int rcd = t->dist->allgather(c.leaf_start, t->d_gls, (size_t)t->lsstride * sizeof(int32_t), s);
         if (rcd) return rcd;
-        // the send / receive counts of the exchange have to be known to the host: one small copy per round (sharded runs are host-paced anyway)
-        std::vector<int32_t> &gls = t->h_gls;
-        gls.resize((size_t)R * t->lsstride);
-        RL_HIP(hipMemcpyAsync(gls.data(), t->d_gls, gls.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        RL_HIP(hipStreamSynchronize(s));
-        auto len_of = [&](int r, int l) { return (long long)gls[(size_t)r * t->lsstride + l + 1] - gls[(size_t)r * t->lsstride + l]; };
-        std::vector<int32_t> &own = t->h_own; own.assign((size_t)MS, 0);
-        {   // owners: largest leaf first onto the least loaded rank (every rank computes the same map from the same table)
-            std::vector<long long> glen((size_t)nseg, 0), load((size_t)R, 0);
-            std::vector<int32_t> order((size_t)nseg);
-            for (int l = 0; l < nseg; l++) { order[l] = l; for (int r = 0; r < R; r++) glen[l] += len_of(r, l); }
-            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return glen[a] > glen[b]; });
-            for (int l : order) {
-                if (glen[l] == 0) { own[l] = l % R; continue; }
-                int o = 0;
-                for (int r = 1; r < R; r++) if (load[r] < load[o]) o = r;
-                own[l] = o; load[o] += glen[l];
-            }
-        }
-        std::vector<long long> &tab = t->h_xtab; tab.assign((size_t)MS * (R + 1), 0);       // pack_off [MS] | asm_off [R][MS]
         std::vector<int64_t> scount(R), sdispl(R), rcount(R), rdispl(R);
-        long long cur = 0;
-        for (int d = 0; d < R; d++) {
-            sdispl[d] = cur * 8;
-            for (int l = 0; l < nseg; l++) if (own[l] == d) { tab[l] = cur; cur += 2 * len_of(me, l); }
-            scount[d] = cur * 8 - sdispl[d];
+        const bool dev_plan = t->d_xmail != nullptr && nseg <= kPlanMaxSeg && R <= 64;
+        if (dev_plan) {
+            // the plan on the device; the host only needs the byte counts of the transfers and reads them from a pinned mailbox below, after it has
+            // enqueued the pack kernel (k_plan_exchange)
+            hipLaunchKernelGGL(k_plan_exchange, dim3(1), dim3(64), 0, s, (const int32_t *)t->d_gls, R, t->lsstride, nseg, MS, me, t->d_own, t->d_xtab, t->d_xmail, ++t->xmail_tag);
+        } else {
+            // the send / receive counts of the exchange have to be known to the host: one small copy per round (sharded runs are host-paced anyway)
+            std::vector<int32_t> &gls = t->h_gls;
+            gls.resize((size_t)R * t->lsstride);
+            RL_HIP(hipMemcpyAsync(gls.data(), t->d_gls, gls.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            RL_HIP(hipStreamSynchronize(s));
+            auto len_of = [&](int r, int l) { return (long long)gls[(size_t)r * t->lsstride + l + 1] - gls[(size_t)r * t->lsstride + l]; };
+            std::vector<int32_t> &own = t->h_own; own.assign((size_t)MS, 0);
+            {   // owners: largest leaf first onto the least loaded rank (every rank computes the same map from the same table)
+                std::vector<long long> glen((size_t)nseg, 0), load((size_t)R, 0);
+                std::vector<int32_t> order((size_t)nseg);
+                for (int l = 0; l < nseg; l++) { order[l] = l; for (int r = 0; r < R; r++) glen[l] += len_of(r, l); }
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return glen[a] > glen[b]; });
+                for (int l : order) {
+                    if (glen[l] == 0) { own[l] = l % R; continue; }
+                    int o = 0;
+                    for (int r = 1; r < R; r++) if (load[r] < load[o]) o = r;
+                    own[l] = o; load[o] += glen[l];
+                }
+            }
+            std::vector<long long> &tab = t->h_xtab; tab.assign((size_t)MS * (R + 1), 0);       // pack_off [MS] | asm_off [R][MS]
+            long long cur = 0;
+            for (int d = 0; d < R; d++) {
+                sdispl[d] = cur * 8;
+                for (int l = 0; l < nseg; l++) if (own[l] == d) { tab[l] = cur; cur += 2 * len_of(me, l); }
+                scount[d] = cur * 8 - sdispl[d];
+            }
+            cur = 0;
+            for (int r = 0; r < R; r++) {
+                rdispl[r] = cur * 8;
+                for (int l = 0; l < nseg; l++) if (own[l] == me) { tab[(size_t)MS * (1 + r) + l] = cur; cur += 2 * len_of(r, l); }
+                rcount[r] = cur * 8 - rdispl[r];
+            }
+            RL_HIP(hipMemcpyAsync(t->d_own, own.data(), (size_t)MS * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            RL_HIP(hipMemcpyAsync(t->d_xtab, tab.data(), tab.size() * sizeof(long long), hipMemcpyHostToDevice, s));
         }
-        cur = 0;
-        for (int r = 0; r < R; r++) {
-            rdispl[r] = cur * 8;
-            for (int l = 0; l < nseg; l++) if (own[l] == me) { tab[(size_t)MS * (1 + r) + l] = cur; cur += 2 * len_of(r, l); }
-            rcount[r] = cur * 8 - rdispl[r];
-        }
-        RL_HIP(hipMemcpyAsync(t->d_own, own.data(), (size_t)MS * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        RL_HIP(hipMemcpyAsync(t->d_xtab, tab.data(), tab.size() * sizeof(long long), hipMemcpyHostToDevice, s));
         const LeafExchange lx{t->d_own, t->d_xtab, t->d_xtab + MS};
-        hipLaunchKernelGGL(k_chain_pack, dim3(nseg, 2), dim3(kThreads), 0, s, (const double *)lb.xs, lb.cap_n, (const int32_t *)c.leaf_start, nseg, lx, t->d_send);
+        hipLaunchKernelGGL(k_chain_pack, dim3(nseg, 2, kLeafXferZ), dim3(kThreads), 0, s, (const double *)lb.xs, lb.cap_n, (const int32_t *)c.leaf_start, nseg, lx, t->d_send);
+        if (dev_plan) {       // the mailbox: the tag is stored last (release); a device error or a dead peer must end the wait
+            const auto t0w = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            while (__atomic_load_n(&t->h_xmail[4 * R], __ATOMIC_ACQUIRE) != t->xmail_tag) {
+                if ((++spins & 0xffff) == 0) {
+                    const hipError_t q = hipStreamQuery(s);
+                    if (q != hipSuccess && q != hipErrorNotReady) return fail(RL_ERR_HIP, std::string("device error before the leaf-owner exchange: ") + hipGetErrorString(q));
+                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0w).count() > t->dist_timeout_s)
+                        return fail(RL_ERR_COMM, "timed out waiting for the plan of the leaf-owner exchange (a rank of the job is missing from a collective?)");
+                }
+            }
+            for (int r = 0; r < R; r++) { scount[r] = t->h_xmail[r]; sdispl[r] = t->h_xmail[R + r]; rcount[r] = t->h_xmail[2 * R + r]; rdispl[r] = t->h_xmail[3 * R + r]; }
+        }
         rcd = t->dist->alltoallv(t->d_send, scount.data(), sdispl.data(), t->d_gx, rcount.data(), rdispl.data(), s);
         if (rcd) return rcd;
         hipLaunchKernelGGL(k_plan_global, dim3(1), dim3(64), 0, s, (const int32_t *)t->d_gls, R, t->lsstride, nseg, t->gchain, (const int32_t *)t->d_own, me);
-        hipLaunchKernelGGL(k_chain_assemble, dim3(nseg, 2), dim3(kThreads), 0, s, (const double *)t->d_gx, (const int32_t *)t->d_gls, R, t->lsstride, nseg, lx,
+        hipLaunchKernelGGL(k_chain_assemble, dim3(nseg, 2, kLeafXferZ), dim3(kThreads), 0, s, (const double *)t->d_gx, (const int32_t *)t->d_gls, R, t->lsstride, nseg, lx,
                            t->gchain, me);
         ChainSource gsrc{t->gchain.xs, t->gchain.xs + t->gchain.cap_n, nullptr, nullptr, nullptr, nullptr};
         enqueue_chain(t, t->gchain, gsrc);
@@ -1293,14 +1324,18 @@ static int enqueue_round(rl_trainer *t)
     hipLaunchKernelGGL(k_export_tree, dim3(1), dim3(kThreads), 0, s, c, t->ens, m);
     RL_HIP(hipGetLastError());
     // per-round training metric (LambdaMART.java:216)
-    const bool use_side = !t->dist && !t->has_valid;
-    if (use_side && t->side_pending) RL_HIP(hipStreamWaitEvent(s, t->ev_metric, 0));     // the previous round's metric still reads d_ndcg
+    // (sharded runs, round 6: the per-query values are gathered on the main stream -- one communicator, one stream -- and the float mean over the
+    // gathered lists runs on the side stream beside the next round's lambdas, as the one-GPU mean does)
+    const bool use_side = !t->has_valid;
+    if (use_side && t->side_pending) RL_HIP(hipStreamWaitEvent(s, t->ev_metric, 0));     // the previous round's metric still reads d_ndcg (sharded: the gathered copy)
     int rc = launch_rank(t, t->tr, c.scores, t->tr.d_ndcg, true);      // also the ranking of round m+1's lambdas
     if (rc != RL_OK) return rc;
     if (use_side) {
+        const double *mq = t->tr.d_ndcg; int mQ = t->tr.Q;
+        if (t->dist) { rc = gather_queries(t, t->tr.d_ndcg, &mq); if (rc != RL_OK) return rc; mQ = t->Qglobal; }
         RL_HIP(hipEventRecord(t->ev_ranked, s));
         RL_HIP(hipStreamWaitEvent(t->side, t->ev_ranked, 0));
-        enqueue_metric_mean(t, t->tr.d_ndcg, t->tr.Q, c.round_metric + 2 * (size_t)m, t->side);
+        enqueue_metric_mean(t, mq, mQ, c.round_metric + 2 * (size_t)m, t->side);
         RL_HIP(hipEventRecord(t->ev_metric, t->side));
         t->side_pending = true;
     } else if (t->dist) {
@@ -1484,6 +1519,8 @@ int rl_create(const rl_params *p, rl_trainer **out)
     RL_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
     RL_HIP(hipEventCreateWithFlags(&t->ev_ranked, hipEventDisableTiming)); RL_HIP(hipEventCreateWithFlags(&t->ev_metric, hipEventDisableTiming));
     t->lam_streams = !(getenv("RLHIP_LAMBDA_STREAMS") && atoi(getenv("RLHIP_LAMBDA_STREAMS")) == 0);
+    if (const char *e = getenv("RLHIP_LAMBDA_SIDE")) t->lam_side = std::max(0, std::min(3, atoi(e)));
+    t->lam_compact = getenv("RLHIP_LAMBDA_COMPACT") && atoi(getenv("RLHIP_LAMBDA_COMPACT")) != 0;
     if (t->lam_streams) {
         RL_HIP(hipEventCreateWithFlags(&t->ev_lam_fork, hipEventDisableTiming));
         for (int i = 0; i < 3; i++) { RL_HIP(hipStreamCreateWithFlags(&t->lam_s[i], hipStreamNonBlocking)); RL_HIP(hipEventCreateWithFlags(&t->ev_lam_join[i], hipEventDisableTiming)); }
@@ -1550,6 +1587,7 @@ void rl_destroy(rl_trainer *t)
     for (auto e : t->ev_free) (void)hipEventDestroy(e);
     if (t->stream) (void)hipStreamDestroy(t->stream);
     if (t->h_progress) (void)hipHostFree(t->h_progress);
+    if (t->h_xmail) (void)hipHostFree(t->h_xmail);
     if (t->tie_buf) (void)hipFree(t->tie_buf);
     if (t->tie_pin) (void)hipHostFree(t->tie_pin);
     for (void *q : t->pinned) (void)hipHostFree(q);
@@ -1685,7 +1723,8 @@ int rl_init(rl_trainer *t)
     // rows of a ranked list whose pairs the lambda loop visits (LambdaMART.java:375-377: j <= cutoff or k <= cutoff); for
     // NDCG / DCG / ERR row `cutoff` itself only holds zero swap changes
     c.k = (t->p.metric == RL_METRIC_MAP) ? t->p.metric_k + 1 : t->p.metric_k;
-    c.rank = t->rank; c.n_ranks = t->n_ranks;
+    c.rank = t->rank; c.n_ranks = t->n_ranks; c.sharded = t->dist ? 1 : 0;
+    if (c.sharded) c.skip_last = 0;       // (the last split's lambda^2 sums travel with its histogram's all-reduce)
 
     // ---- K9: thresholds + bins on the device ----------------------------------------------------
     float *Xt = nullptr;
@@ -1921,6 +1960,12 @@ int rl_init(rl_trainer *t)
     }
     hipLaunchKernelGGL(k_binning, dim3(F, slices), dim3(kThreads), (size_t)TS * 8, s, (const float *)Xt, N, Npad, TS, (const float *)d_thr,
                        (const int32_t *)d_nthr, d_bins, d_gbins, c.cum_cnt, c.vcol);
+    c.cum_cnt_loc = nullptr;
+    if (t->dist && !getenv("RLHIP_DIST_COUNT_PASS")) {       // this rank's own root counts, kept beside the all-reduced ones (RLHIP_DIST_COUNT_PASS=1: round 5's count pass + two-pass partition)
+        RL_HIP(t->pool.alloc(&c.cum_cnt_loc, (size_t)c.NC * F * TS));
+        RL_HIP(hipMemsetAsync(c.cum_cnt_loc, 0, (size_t)c.NC * F * TS * sizeof(int32_t), s));
+        RL_HIP(hipMemcpyAsync(c.cum_cnt_loc, c.cum_cnt, (size_t)F * TS * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    }
     if (t->dist) { int rcd = t->dist->allreduce(c.cum_cnt, (size_t)F * TS, DT_I32, OP_SUM, s); if (rcd) return rcd; }
     {
         uint16_t *d_dbins = nullptr;
@@ -1951,6 +1996,11 @@ int rl_init(rl_trainer *t)
     RL_HIP(t->pool.alloc(&d_mode, (size_t)F));
     c.mode = d_mode;
     hipLaunchKernelGGL(k_cumulate_counts, dim3(F), dim3(64), 0, s, TS, (const int32_t *)d_nthr, c.cum_cnt, d_mode);
+    if (c.cum_cnt_loc) {       // (the mode bins are the GLOBAL ones: the local pass only cumulates)
+        int32_t *d_mode_scratch = nullptr;
+        RL_HIP(t->pool.alloc(&d_mode_scratch, (size_t)F));
+        hipLaunchKernelGGL(k_cumulate_counts, dim3(F), dim3(64), 0, s, TS, (const int32_t *)d_nthr, c.cum_cnt_loc, d_mode_scratch);
+    }
     {   // columns whose bins come in runs (nine in ten documents outside the mode bin are followed by an equal bin: a quad agrees 3 times in 4)
         unsigned long long *d_rs = nullptr;
         RL_HIP(t->pool.alloc(&d_rs, (size_t)2 * F));
@@ -2299,6 +2349,11 @@ int rl_init(rl_trainer *t)
             RL_HIP(t->pool.alloc(&t->d_send, (size_t)2 * N + 2));
             RL_HIP(t->pool.alloc(&t->d_own, (size_t)c.MAXN + 1)); RL_HIP(t->pool.alloc(&t->d_xtab, (size_t)(c.MAXN + 1) * (t->n_ranks + 1)));
             RL_HIP(t->pool.alloc(&t->d_gls, (size_t)t->n_ranks * t->lsstride));
+            // pinned mailbox of k_plan_exchange (RLHIP_DIST_HOST_PLAN=1: the host plan behind a stream synchronisation, as until round 5)
+            if (!getenv("RLHIP_DIST_HOST_PLAN") && !t->h_xmail && hipHostMalloc((void **)&t->h_xmail, (size_t)(4 * 64 + 1) * sizeof(long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+                memset(t->h_xmail, 0, (size_t)(4 * 64 + 1) * sizeof(long long));
+                if (hipHostGetDevicePointer((void **)&t->d_xmail, t->h_xmail, 0) != hipSuccess) { t->d_xmail = nullptr; (void)hipGetLastError(); }
+            } else (void)hipGetLastError();
             RL_HIP(t->pool.alloc(&t->d_gres, (size_t)t->n_ranks * 2 * (c.MAXN + 1) + 8));
             RL_HIP(t->pool.alloc(&t->d_qsend, (size_t)t->Qmax)); RL_HIP(t->pool.alloc(&t->d_qgath, (size_t)t->n_ranks * t->Qmax));
             RL_HIP(t->pool.alloc(&t->d_qcat, (size_t)t->Qglobal)); RL_HIP(t->pool.alloc(&t->d_allQ, (size_t)t->n_ranks));

@@ -143,6 +143,38 @@ def test_fullsize_oracle_parity(shape, rounds, strict):
     assert stats.get("plateau", 0) == 0
 
 
+def test_c1_forty_rounds_against_the_oracle():
+    """The boosting loop learning/tree/LambdaMART.java:169-272 followed for 40 rounds at BASELINE.json configs[1]'s full size (1.2 M x 136, 31 leaves,
+    default flags) against the oracle -- where the driver's own GPU run can see it (tools/long_parity.py follows 1000 rounds, profiles/r05t_* / r06*):
+    every round's tree (no split may store another (feature, threshold)), the float train metric and the scores of all documents bit for bit;
+    lambda and weight of all documents every tenth round.  Late rounds differ from the first three: chain-like trees, 15+ growth steps, lambdas
+    whose magnitudes span many binades."""
+    rounds = 40
+    n_docs, n_feat, kind, _, n_leaves = synth.SHAPES["c1"]
+    X, lab, qoff, Q = synth.make_shard(n_docs, n_feat, kind, 0, 1)
+    o = O.Oracle(X, lab, qoff, n_trees=rounds, n_leaves=n_leaves, n_threads=os.cpu_count() or 8)
+    o.init()
+    g = N.Trainer(n_trees=rounds, n_leaves=n_leaves)
+    g.set_train(X, lab, qoff)
+    g.init()
+    stats = {}
+    t_or = 0.0
+    for r in range(rounds):
+        t0 = time.time()
+        to, tmo, _, _ = o.round()
+        t_or += time.time() - t0
+        tg, tmg, _, _ = g.boost_round()
+        if r % 10 == 0 or r == rounds - 1:
+            assert np.array_equal(g.array("LAMBDA").view(np.int64), o.lambdas().view(np.int64)), r
+            assert np.array_equal(g.array("WEIGHT").view(np.int64), o.weights().view(np.int64)), r
+        assert_equivalent(to, tg, X, "c1 round %d" % r, stats)
+        assert np.float32(tmo).view(np.uint32) == np.float32(tmg).view(np.uint32), r
+        assert np.array_equal(g.array("SCORE").view(np.int64), o.scores().view(np.int64)), r
+    print("\n[c1 x %d rounds] splits compared %d, tie-resolved differently %d; oracle %.2f s/round; growth steps per tree %.1f"
+          % (rounds, stats.get("splits", 0), stats.get("plateau", 0), t_or / rounds, float(g.array("GROW_STATS")[0]) / rounds))
+    assert stats.get("splits", 0) == 30 * rounds and stats.get("plateau", 0) == 0
+
+
 def test_ensemble_eval_10k_trees_1m_rows():
     """BASELINE.json configs[4] in the -m gpu suite at 1/100 of its rows: a 10 000-tree, 31-leaf ensemble (100 trained rounds tiled, as bench.py
     --workload infer builds it) scores 1 000 003 device-resident rows (a partial last tile).  The oracle's Ensemble.eval (learning/tree/
