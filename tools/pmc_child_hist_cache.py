@@ -20,10 +20,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 shape = sys.argv[1] if len(sys.argv) > 1 else "c2"
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 12
-SETS = ["FETCH_SIZE", "WRITE_SIZE", "TCP_TCC_READ_REQ_sum", "TCC_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA_RDREQ_sum", "TCC_EA_RDREQ_32B_sum"]
+SETS = ["FETCH_SIZE", "WRITE_SIZE", "TCP_TCC_READ_REQ_sum", "TCC_REQ_sum", "TCC_READ_sum", "TCC_READ_SECTORS_sum", "TCC_HIT_sum", "TCC_MISS_sum",
+        "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"]       # (gfx950 names: rocprofv3 --list-avail)
 
 
 def one_pass(ctr):
+    """per tree (the launches between two root passes, in dispatch order): the counter of every k_hist<false> launch"""
     d = tempfile.mkdtemp(prefix="rlhip_pmc_", dir="/tmp")
     cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "bench.py"),
            "--shape", shape, "--steps", str(rounds - 1), "--warmup", "1", "--plain"]
@@ -34,7 +36,13 @@ def one_pass(ctr):
     rows = con.execute("select kernel_name, dispatch_id, sum(value) from counters_collection where counter_name=? group by kernel_name, dispatch_id order by dispatch_id", (ctr,)).fetchall()
     con.close()
     shutil.rmtree(d, ignore_errors=True)
-    return np.array([v for name, _, v in rows if "k_hist<false" in name], dtype=np.float64)
+    trees = []
+    for name, _, v in rows:
+        if "k_hist<true" in name:
+            trees.append([])
+        elif "k_hist<false" in name and trees:
+            trees[-1].append(float(v))
+    return trees
 
 
 def step_log():
@@ -59,28 +67,37 @@ def step_log():
         key = (int(tree), int(step))
         a = steps.setdefault(key, [0, 0])
         a[0] += int(bdocs); a[1] += int(pdocs)
-    return n_docs, n_feat, [steps[k] for k in sorted(steps)]
+    return n_docs, n_feat, steps
 
 
 vals = {}
 for c in SETS:
     v = one_pass(c)
-    if v is None:
-        print("# pass %s failed (counter not available on this box?)" % c)
+    if v is None or len(v) == 0:
+        print("# pass %s gave nothing (counter not available on this box?)" % c)
         continue
     vals[c] = v
 n_docs, F, steps = step_log()
-nl = min(len(v) for v in vals.values())
-print("# %s, %d rounds: %d launches of k_hist<false> per pass (%s), %d growth steps with work in the step log" % (shape, rounds, nl, sorted(set(len(v) for v in vals.values())), len(steps)))
-# a launch without work (a step enqueued behind a finished tree) fetches next to nothing: the launches with work, in order, are the logged steps
-fetch = vals["FETCH_SIZE"][:nl] * 1024.0
-work = np.nonzero(fetch > 64 * 1024)[0]
-if len(work) != len(steps):
-    print("# WARNING: %d launches with traffic against %d logged steps: per-class algorithmic bytes are approximate" % (len(work), len(steps)))
-m = min(len(work), len(steps))
-work = work[:m]
-built = np.array([s[0] for s in steps[:m]], dtype=np.float64)
+# launch i of a tree is its growth step i; the launches behind a tree's last logged step are the steps the host had enqueued beyond its end (no work)
+ntree = min(len(v) for v in vals.values())
+per_tree = {}
+for (tree, step), a in steps.items():
+    per_tree.setdefault(tree, []).append((step, a))
+tree_ids = sorted(per_tree)
+print("# %s, %d rounds: %d trees in every pass, %d in the step log; child-pass launches per tree %s, logged steps per tree %s"
+      % (shape, rounds, ntree, len(tree_ids), [len(t) for t in next(iter(vals.values()))][:ntree], [len(per_tree[t]) for t in tree_ids]))
+built = []
+sel_idx = []          # (tree, launch) of every logged step
+for ti, t in enumerate(tree_ids[:ntree]):
+    for li, (step, a) in enumerate(sorted(per_tree[t])):
+        if all(li < len(v[ti]) for v in vals.values()):
+            built.append(a[0]); sel_idx.append((ti, li))
+built = np.array(built, dtype=np.float64)
 alg = built * (2.0 * F + 12.0)
+m = len(built)
+nl = m
+work = np.arange(m)
+vals = {c: np.array([v[ti][li] for ti, li in sel_idx], dtype=np.float64) for c, v in vals.items()}
 big = built >= 400000          # ~ the steps whose chunks are balanced over two blocks per CU
 for label, sel in (("steps that fill the chip (>= 400 k documents accumulated)", big), ("small steps", ~big), ("all steps", np.ones(m, bool))):
     k = int(sel.sum())
@@ -93,14 +110,18 @@ for label, sel in (("steps that fill the chip (>= 400 k documents accumulated)",
             print("  %-22s %10.2f MB a launch   = %.2f x algorithmic" % (c, x.mean() * 1024 / 1e6, x.sum() * 1024 / alg[sel].sum()))
         elif c == "TCP_TCC_READ_REQ_sum":
             print("  %-22s %10.0f k requests   (x 64 B = %.2f MB = %.2f x algorithmic: what the CUs ask the L2 for)" % (c, x.mean() / 1e3, x.mean() * 64 / 1e6, x.sum() * 64 / alg[sel].sum()))
-        elif c.startswith("TCC_EA_RDREQ"):
-            print("  %-22s %10.0f k requests   (x 64 B = %.2f MB)" % (c, x.mean() / 1e3, x.mean() * 64 / 1e6))
+        elif c == "TCC_READ_SECTORS_sum":
+            print("  %-22s %10.0f k sectors    (x 32 B = %.2f MB = %.2f x algorithmic: what the L2 delivers)" % (c, x.mean() / 1e3, x.mean() * 32 / 1e6, x.sum() * 32 / alg[sel].sum()))
+        elif c.startswith("TCC_EA0_RDREQ"):
+            print("  %-22s %10.0f k requests" % (c, x.mean() / 1e3))
         else:
             print("  %-22s %10.0f k" % (c, x.mean() / 1e3))
     if "TCC_HIT_sum" in vals and "TCC_MISS_sum" in vals:
         h, mi = vals["TCC_HIT_sum"][:nl][work][sel].sum(), vals["TCC_MISS_sum"][:nl][work][sel].sum()
         print("  L2 hit rate %.3f" % (h / max(h + mi, 1.0)))
-    if "TCC_EA_RDREQ_sum" in vals and "TCC_EA_RDREQ_32B_sum" in vals:
-        a, b = vals["TCC_EA_RDREQ_sum"][:nl][work][sel].sum(), vals["TCC_EA_RDREQ_32B_sum"][:nl][work][sel].sum()
-        print("  memory reads: %.2f MB a launch as (requests - 32 B ones) x 64 + 32 B ones x 32 = %.2f x algorithmic; %.0f %% of the requests are 32 B"
-              % (((a - b) * 64 + b * 32) / k / 1e6, ((a - b) * 64 + b * 32) / alg[sel].sum(), 100.0 * b / max(a, 1.0)))
+    if all(("TCC_EA0_RDREQ%s_sum" % q) in vals for q in ("", "_32B", "_64B", "_128B")):
+        g = lambda q: vals["TCC_EA0_RDREQ%s_sum" % q][:nl][work][sel].sum()
+        a, b32, b64, b128 = g(""), g("_32B"), g("_64B"), g("_128B")
+        byts = b32 * 32 + b64 * 64 + b128 * 128
+        print("  memory reads by size: %.0f %% 32 B, %.0f %% 64 B, %.0f %% 128 B of %.0f k requests a launch = %.2f MB = %.2f x algorithmic"
+              % (100.0 * b32 / max(a, 1.0), 100.0 * b64 / max(a, 1.0), 100.0 * b128 / max(a, 1.0), a / k / 1e3, byts / k / 1e6, byts / alg[sel].sum()))
