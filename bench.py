@@ -257,21 +257,22 @@ def respawn(n):
 
 
 def scaling_model(docs_per_rank, world, steps_tree=10.8, ar_bytes=None):
-    """MODELLED (never fitted to a multi-GPU run) milliseconds per round of a sharded run, from the one-GPU c2 measurements of round 5
-    (profiles/r05*_c2_kernel_stats.txt): kernels whose work is per document scale with the shard; a growth step of the sharded path (count + scatter
-    partition, child histograms, limb reduce, all-reduce, finish + bookkeeping: the round-4 kernels) keeps its launch / latency floor and pays one
-    all-reduce (assumed 20 us + bytes at 40 GB/s effective ring bandwidth per rank over xGMI); the float chain of the largest leaf has one owner."""
+    """MODELLED (never fitted to a multi-GPU run) milliseconds per round of a sharded run, from the ONE-RANK run of the sharded code path at c2 of round 6
+    (profiles/r06f_sharded_one_rank_kernel_stats.txt / _timeline.txt: everything of the N > 1 path but the wire, 385 rounds/s against 429 of the plain path):
+    kernels whose work is per document scale with the shard; a growth step (single-pass partition from local counts, child histograms, limb reduce,
+    all-reduce, k_fin2<DIST>, k_select2) is ~112 us at 3.77 M documents per rank, of which ~70 us are the latency floor of its five dependent launches
+    whatever the shard size, and pays one all-reduce (ASSUMED 20 us + bytes at 40 GB/s effective ring bandwidth per rank over xGMI); the float chain of
+    the largest leaf has ONE owner rank (~60 % of all documents early in training)."""
     share = docs_per_rank / 3.77e6
     if ar_bytes is None:
         ar_bytes = 2.2 * 559e3          # ~2.2 slots of 559 KB per step on average at F = 136
-    t_doc = (0.37 + 0.13 + 0.30 + 0.015) * share                   # lambdas, ranking, root pass + finish, score update (profiles/r05r_c2_kernel_stats.txt)
-    t_step = steps_tree * (0.075 + 0.048 * share + 0.020 + ar_bytes / 40e9 * 1e3)
-    # leaf sums: a leaf's float chain is one sequence with one owner rank; the largest leaf holds ~60 % of ALL documents early in training, so its owner
-    # evaluates 0.6 x (documents of the whole job) whatever the rank count; + the exchange and its host hand-over when sharded
-    t_leaf = 0.30 * max(share, 0.6 * share * world) + (0.15 if world > 1 else 0.0)
+    t_doc = (0.355 + 0.133 + 0.30 + 0.015) * share                 # lambdas, ranking + per-query metric, root pass + reduce + finish, score update
+    t_step = steps_tree * (0.070 + 0.042 * share + (0.020 + ar_bytes / 40e9 * 1e3 if world > 1 else 0.0))
+    # leaf sums: gather in leaf order + exchange (pack, all-to-all, assemble) scale with the shard; the chains of a rank's own leaves with what it owns
+    t_leaf = 0.21 * max(share, 0.6 * share * world) + 0.12 * share + 0.08
     return {"modelled_ms_per_round": t_doc + t_step + t_leaf, "modelled_rounds_per_s": 1000.0 / (t_doc + t_step + t_leaf), "world": world,
             "docs_per_rank": docs_per_rank, "growth_steps_per_tree": steps_tree, "allreduce_bytes_per_call": ar_bytes,
-            "note": "modelled = per-document kernels x shard share + growth steps x (launch floor + shard's histogram work + one all-reduce) + leaf sums"}
+            "note": "modelled = per-document kernels x shard share + growth steps x (70 us floor + 42 us x share + one all-reduce) + leaf sums (the largest leaf's chain has one owner)"}
 
 
 def main():
@@ -582,6 +583,12 @@ def main():
     if sustained is not None:
         out["config"]["sustained_rounds_per_s"] = sustained
         out["config"]["sustained_over_rounds"] = args.sustain
+    bb = g.array("BUBBLES")
+    out["config"]["host_bubbles"] = {
+        "what": "device wall-clock time the main stream idled behind a host decision, averaged over the whole run of this trainer (RL_ARR_BUBBLES): "
+                "the bookkeeping that ends a tree -> first instruction of the leaf table (one empty growth step was already enqueued); the leaf chain's last "
+                "stitch -> the leaf outputs (the host looks at the stitch's result before it enqueues anything else)",
+        "tree_end_to_leaf_table_us": 0.01 * float(bb[0]) / max(int(bb[1]), 1), "stitch_to_leaf_output_us": 0.01 * float(bb[2]) / max(int(bb[3]), 1), "trees": int(bb[1])}
     ts = g.array("TIE_STATS")
     out["config"]["tie_break"] = {
         "mode": "lazy Java-order (exact ties re-decided in the reference's summation order, HISTORY.md 4.13; sharded runs gather the chain nodes and do the same)"

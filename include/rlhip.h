@@ -295,9 +295,11 @@ enum {
                                    the Java-order derivation chain, nodes in the chain, documents in the chain} for a committed split whose best candidate was tied */
     RL_ARR_PHASE_CLOCKS = 16,   /* int64[64][32] device wall-clock stamps (10 ns) inside the last 64 growth steps; all zero unless the
                                    library was built with -DRL_PHASE_CLOCKS (tools/phase_clocks.py) */
-    RL_ARR_BLOCK_TRACE = 22     /* int64[64][3][2048][8] entry / phase / exit stamps (10 ns; [0] entry, [7] exit) of every working block of the partition / child-histogram /
+    RL_ARR_BLOCK_TRACE = 22,    /* int64[64][3][2048][8] entry / phase / exit stamps (10 ns; [0] entry, [7] exit) of every working block of the partition / child-histogram /
                                    finish kernels in the growth steps of the tree named by RLHIP_TRACE_TREE (-DRL_PHASE_CLOCKS builds,
                                    tools/step_trace.py); RL_ERR_STATE when no trace was requested */
+    RL_ARR_BUBBLES = 23         /* int64[4] cumulative device wall-clock time (10 ns units) the main stream idled behind host decisions: [0] from the bookkeeping that ended a
+                                   tree to the leaf table's first instruction, [1] trees, [2] from a leaf chain's last stitch to the leaf outputs, [3] rounds (round 6) */
 };
 /* The device's two exp implementations (rho of learning/tree/LambdaMART.java:383) on n arguments: the branch-free one the
  * lambda kernels use and the literal fdlibm e_exp transcription; both must equal StrictMath.exp bit for bit. */

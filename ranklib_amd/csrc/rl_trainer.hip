@@ -2283,7 +2283,7 @@ int rl_init(rl_trainer *t)
     RL_HIP(t->pool.alloc(&c.tile_desc, (size_t)c.nTiles)); RL_HIP(hipMemset(c.tile_desc, 0, (size_t)c.nTiles * 8));
     RL_HIP(t->pool.alloc(&c.tile_gdesc, (size_t)c.nTiles / 64 + kSpec + 2)); RL_HIP(hipMemset(c.tile_gdesc, 0, ((size_t)c.nTiles / 64 + kSpec + 2) * 8));
     RL_HIP(t->pool.alloc(&c.grow_stats, (size_t)4)); RL_HIP(hipMemset(c.grow_stats, 0, 16));
-    RL_HIP(t->pool.alloc(&c.grow_docs, (size_t)4)); RL_HIP(hipMemset(c.grow_docs, 0, 32));
+    RL_HIP(t->pool.alloc(&c.grow_docs, (size_t)10)); RL_HIP(hipMemset(c.grow_docs, 0, 80));      // ([4..9]: bubble stamps, RL_ARR_BUBBLES)
     c.steplog = nullptr;
     if (getenv("RLHIP_STEPLOG")) { RL_HIP(t->pool.alloc(&c.steplog, (size_t)8 + 8 * kStepLogCap)); RL_HIP(hipMemset(c.steplog, 0, ((size_t)8 + 8 * kStepLogCap) * sizeof(int32_t))); }
     RL_HIP(t->pool.alloc(&c.clk, (size_t)64 * 32));
@@ -2684,6 +2684,7 @@ int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes)
     case RL_ARR_NDCG_PER_QUERY: src = c.ndcg_q; bytes = (size_t)c.Q * 8; break;
     case RL_ARR_GROW_STATS: src = c.grow_stats; bytes = 16; break;
     case RL_ARR_GROW_DOCS: src = c.grow_docs; bytes = 32; break;
+    case RL_ARR_BUBBLES: src = c.grow_docs + 4; bytes = 32; break;
     case RL_ARR_SPARSE_INFO: {
         const int64_t v[8] = {c.sp_on ? c.sp_ngroups : 0, t->sp_entries, c.sp_on ? c.numFG - c.sp_ngroups : c.numFG, t->sp_cols,
                               c.crows ? t->cr_groups : 0, (int64_t)t->cr_entries, (int64_t)t->cr_overflow, c.cr_stride};

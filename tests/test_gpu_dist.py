@@ -67,6 +67,17 @@ def test_one_rank_distributed_paths_equal_plain_path():
     same(ref, single(*CFG, dist_mode="rccl1"))     # RCCL transport (dlopen'ed librccl), 1-rank communicator
 
 
+def test_one_rank_sharded_path_beyond_one_block_row_of_chunks():
+    """Round 6: at 9 000 documents a growth step has fewer chunks than a balanced step starts at (28), and a one-rank communicator that balanced
+    its chunks while k_hist_reduce cut the nodes by the per-node rule passed every test -- and grew other trees from 60 000 documents on (bench.py
+    --sharded-one-rank: NDCG@10 0.56 against 0.66 at c2; tools/dist_scale_check.py).  Here: 120 000 x 24, 31 leaves, steps of ~100 balanced chunks, both
+    transports; the sharded path must run the plain path's trees."""
+    big = (120000, 24, "mslr", 3, 31, 3)
+    ref = single(*big)
+    same(ref, single(*big, dist_mode="rccl1"))
+    same(ref, single(*big, dist_mode="cb1"))
+
+
 CFG2K = (16384, 24, "ns", 3, 12, 4)       # shards of 8199 / 8185 documents: different ceil(log2(N + 1)), one lambda^2 scale for all ranks
 
 
@@ -79,13 +90,15 @@ def test_shard_sizes_straddle_a_power_of_two():
 
 CFG_TIES = (2500, 5, "mslr", 4, 31, 4)    # small nodes, five features: exact ties in every round -- the sharded lazy tie-break has to run (and to agree with one GPU)
 CFG31 = (9000, 24, "mslr", 4, 31, 4)      # 30 growth steps allowed, trees finish after ~10: the ranks must stop enqueuing at the same step
+CFG_BIG = (150000, 24, "mslr", 5, 31, 3)  # shards of 50-75 k documents: steps of many balanced chunks per rank, local left sizes from the ranks' own cumulative counts (round 6)
 
 
 @pytest.mark.parametrize("world,ranker,metric,k,cfg", [(2, "LAMBDAMART", "NDCG", 10, CFG), (3, "LAMBDAMART", "NDCG", 10, CFG),
                                                         (2, "MART", "NDCG", 10, CFG), (2, "LAMBDAMART", "MAP", 0, CFG),
                                                         (3, "LAMBDAMART", "ERR", 10, CFG), (2, "LAMBDAMART", "NDCG", 10, CFG31),
                                                         (3, "MART", "NDCG", 10, CFG31), (2, "LAMBDAMART", "NDCG", 10, CFG2K),
-                                                        (2, "LAMBDAMART", "NDCG", 10, CFG_TIES), (3, "LAMBDAMART", "NDCG", 10, CFG_TIES)])
+                                                        (2, "LAMBDAMART", "NDCG", 10, CFG_TIES), (3, "LAMBDAMART", "NDCG", 10, CFG_TIES),
+                                                        (2, "LAMBDAMART", "NDCG", 10, CFG_BIG), (3, "LAMBDAMART", "NDCG", 10, CFG_BIG)])
 def test_k_shards_equal_one_shard(world, ranker, metric, k, cfg, tmp_path):
     CFG = cfg
     ref = single(*CFG, ranker=ranker, metric=metric, k=k)
