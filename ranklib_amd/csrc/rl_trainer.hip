@@ -1264,20 +1264,20 @@ static int enqueue_round(rl_trainer *t)
             long long cur = 0;
             for (int d = 0; d < R; d++) {
                 sdispl[d] = cur * 8;
-                for (int l = 0; l < nseg; l++) if (own[l] == d) { tab[l] = cur; cur += 2 * len_of(me, l); }
+                if (d != me) for (int l = 0; l < nseg; l++) if (own[l] == d) { tab[l] = cur; cur += 2 * len_of(me, l); }       // (own leaves: not packed, k_chain_assemble)
                 scount[d] = cur * 8 - sdispl[d];
             }
             cur = 0;
             for (int r = 0; r < R; r++) {
                 rdispl[r] = cur * 8;
-                for (int l = 0; l < nseg; l++) if (own[l] == me) { tab[(size_t)MS * (1 + r) + l] = cur; cur += 2 * len_of(r, l); }
+                if (r != me) for (int l = 0; l < nseg; l++) if (own[l] == me) { tab[(size_t)MS * (1 + r) + l] = cur; cur += 2 * len_of(r, l); }
                 rcount[r] = cur * 8 - rdispl[r];
             }
             RL_HIP(hipMemcpyAsync(t->d_own, own.data(), (size_t)MS * sizeof(int32_t), hipMemcpyHostToDevice, s));
             RL_HIP(hipMemcpyAsync(t->d_xtab, tab.data(), tab.size() * sizeof(long long), hipMemcpyHostToDevice, s));
         }
         const LeafExchange lx{t->d_own, t->d_xtab, t->d_xtab + MS};
-        hipLaunchKernelGGL(k_chain_pack, dim3(nseg, 2, kLeafXferZ), dim3(kThreads), 0, s, (const double *)lb.xs, lb.cap_n, (const int32_t *)c.leaf_start, nseg, lx, t->d_send);
+        hipLaunchKernelGGL(k_chain_pack, dim3(nseg, 2, kLeafXferZ), dim3(kThreads), 0, s, (const double *)lb.xs, lb.cap_n, (const int32_t *)c.leaf_start, nseg, lx, t->d_send, me);
         if (dev_plan) {       // the mailbox: the tag is stored last (release); a device error or a dead peer must end the wait
             const auto t0w = std::chrono::steady_clock::now();
             unsigned spins = 0;
@@ -1295,7 +1295,7 @@ static int enqueue_round(rl_trainer *t)
         if (rcd) return rcd;
         hipLaunchKernelGGL(k_plan_global, dim3(1), dim3(64), 0, s, (const int32_t *)t->d_gls, R, t->lsstride, nseg, t->gchain, (const int32_t *)t->d_own, me);
         hipLaunchKernelGGL(k_chain_assemble, dim3(nseg, 2, kLeafXferZ), dim3(kThreads), 0, s, (const double *)t->d_gx, (const int32_t *)t->d_gls, R, t->lsstride, nseg, lx,
-                           t->gchain, me);
+                           t->gchain, me, (const double *)lb.xs, lb.cap_n, (const int32_t *)c.leaf_start);
         ChainSource gsrc{t->gchain.xs, t->gchain.xs + t->gchain.cap_n, nullptr, nullptr, nullptr, nullptr};
         enqueue_chain(t, t->gchain, gsrc);
         if (R > 1) {       // every rank evaluated its own leaves: exchange the 2 L float sums
