@@ -298,6 +298,8 @@ enum {
     RL_ARR_BLOCK_TRACE = 22,    /* int64[64][3][2048][8] entry / phase / exit stamps (10 ns; [0] entry, [7] exit) of every working block of the partition / child-histogram /
                                    finish kernels in the growth steps of the tree named by RLHIP_TRACE_TREE (-DRL_PHASE_CLOCKS builds,
                                    tools/step_trace.py); RL_ERR_STATE when no trace was requested */
+    RL_ARR_PIECE_STATS = 24,    /* int64[2] cumulative, sharded runs with distributed float chains (rl_dist.inc): rounds of the repair loop, pieces re-evaluated from an
+                                   exact start state after a detected window miss */
     RL_ARR_BUBBLES = 23         /* int64[4] cumulative device wall-clock time (10 ns units) the main stream idled behind host decisions: [0] from the bookkeeping that ended a
                                    tree to the leaf table's first instruction, [1] trees, [2] from a leaf chain's last stitch to the leaf outputs, [3] rounds (round 6) */
 };

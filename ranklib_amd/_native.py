@@ -38,7 +38,7 @@ class RlTree(C.Structure):
 RL_FLAG_TIMING, RL_FLAG_SERIAL_CHAIN, RL_FLAG_TIMING_NODES, RL_FLAG_JAVA_ORDER, RL_FLAG_FIRST_TIE = 2, 4, 8, 16, 32
 ARR = dict(LAMBDA=1, WEIGHT=2, SCORE=3, VALID_SCORE=4, NBINS=5, THRESHOLDS=6, BINS=7, ROOT_COUNT=8, ROOT_SUM=9,
            QUANT=10, ROOT_SUM_FIXED=11, NDCG_PER_QUERY=12, CHAIN_STATS=13, CHAIN_MISS=14, GROW_STATS=15, PHASE_CLOCKS=16,
-           ROOT_SUM_JAVA=17, GROW_DOCS=18, SPARSE_INFO=19, STEP_LOG=20, TIE_STATS=21, BLOCK_TRACE=22, BUBBLES=23)
+           ROOT_SUM_JAVA=17, GROW_DOCS=18, SPARSE_INFO=19, STEP_LOG=20, TIE_STATS=21, BLOCK_TRACE=22, BUBBLES=23, PIECE_STATS=24)
 KERNEL = dict(HIST_ROOT=0, HIST_NODE=1, LAMBDA=2)
 
 # every symbol include/rlhip.h declares (tests/test_abi.py checks the .so exports all of them)
@@ -444,7 +444,7 @@ class Trainer:
             "THRESHOLDS": ((F_hist, TS), np.float32), "BINS": ((F_hist, self.N), np.uint16),
             "ROOT_COUNT": ((F_hist, TS), np.int32), "ROOT_SUM": ((F_hist, TS), np.float64), "ROOT_SUM_JAVA": ((F_hist, TS), np.float64),
             "QUANT": ((self.N,), np.int64), "ROOT_SUM_FIXED": ((F_hist, TS, 2), np.int64),
-            "NDCG_PER_QUERY": ((self.Q,), np.float64), "CHAIN_STATS": ((6,), np.int32), "GROW_STATS": ((4,), np.int32), "GROW_DOCS": ((4,), np.int64), "BUBBLES": ((4,), np.int64), "SPARSE_INFO": ((8,), np.int64), "PHASE_CLOCKS": ((64, 32), np.int64), "BLOCK_TRACE": ((64, 3, 2048, 8), np.int64), "STEP_LOG": ((8 + 8 * 8192,), np.int32), "TIE_STATS": ((10,), np.int64), "CHAIN_MISS": ((2, self.cap + 1), np.int32),
+            "NDCG_PER_QUERY": ((self.Q,), np.float64), "CHAIN_STATS": ((6,), np.int32), "GROW_STATS": ((4,), np.int32), "GROW_DOCS": ((4,), np.int64), "BUBBLES": ((4,), np.int64), "PIECE_STATS": ((2,), np.int64), "SPARSE_INFO": ((8,), np.int64), "PHASE_CLOCKS": ((64, 32), np.int64), "BLOCK_TRACE": ((64, 3, 2048, 8), np.int64), "STEP_LOG": ((8 + 8 * 8192,), np.int32), "TIE_STATS": ((10,), np.int64), "CHAIN_MISS": ((2, self.cap + 1), np.int32),
         }
         shape, dt = shapes[name]
         out = np.zeros(shape, dt)

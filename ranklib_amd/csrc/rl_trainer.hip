@@ -145,6 +145,9 @@ struct rl_trainer {
     double *d_gx = nullptr, *d_send = nullptr; int32_t *d_gls = nullptr; int32_t lsstride = 0; float *d_gres = nullptr;     // leaf-owner exchange: receive / send buffers
     int32_t *d_own = nullptr; long long *d_xtab = nullptr;     // owner of every leaf; pack / assemble offsets (rl_dist.inc LeafExchange)
     std::vector<int32_t> h_gls, h_own; std::vector<long long> h_xtab;
+    // round 6, distributed float chains (rl_dist.inc "piece mode"; RLHIP_DIST_OWNER_CHAINS=1: the leaf-owner exchange instead)
+    bool piece_chains = false; double *d_pc_loc = nullptr, *d_pc_all = nullptr, *d_pc_base = nullptr; uint32_t *d_ptab = nullptr, *d_gtab = nullptr, *d_res_loc = nullptr, *d_res_all = nullptr;
+    CrossState xstate{nullptr, nullptr, nullptr}; long long piece_rounds = 0, piece_misses = 0; int32_t piece_force = 0;      // (RLHIP_PIECE_FORCE_MISS=1, a test aid: every piece behind a rank's first is re-evaluated)
     long long *h_xmail = nullptr, *d_xmail = nullptr, xmail_tag = 0;     // pinned mailbox of k_plan_exchange (transfer sizes of the leaf-owner exchange): no stream synchronisation in a round
     double *d_qsend = nullptr, *d_qgath = nullptr, *d_qcat = nullptr; int32_t *d_allQ = nullptr;
     // the same for the validation set (sharded by query like the training set)
@@ -414,6 +417,99 @@ static void enqueue_chain(rl_trainer *t, const ChainBufs &b_in, const ChainSourc
 }
 
 // float s = 0; for (q) s += ndcg_q; s / Q   -- serial for short lists, exact parallel chain otherwise
+// the ordinary repair passes on the segments k_chain_arm has opened (exact start states known), until the host has seen them closed
+static void chain_repair_rounds(rl_trainer *t, const ChainBufs &b, hipStream_t s)
+{
+    const dim3 p1grid((unsigned)((b.cap_chunks * 16 + kThreads - 1) / kThreads), b.A);
+    const dim3 tgrid((unsigned)((b.cap_chunks + kThreads / 64 - 1) / (kThreads / 64)), b.A);
+    const dim3 cgrid((unsigned)((b.cap_chunks / kChainBlock + kThreads / 64) / (kThreads / 64)), b.A);
+    const size_t lds = chain_stitch_lds(b);
+    const unsigned long long seq = ++t->chain_seq;
+    bool hint = b.h_progress != nullptr && t->step_ahead > 0, clean = false;
+    for (int rep = 0; rep < (hint ? kChainRepairsMax : kChainRepairs); rep++) {
+        t->chain_repairs[b.h_progress ? 0 : 1]++;
+        hipLaunchKernelGGL(k_chain_pass1<true>, p1grid, dim3(kThreads), 0, s, b);
+        hipLaunchKernelGGL(k_chain_recentre, dim3(b.maxseg, b.A), dim3(kScanThreads), 0, s, b);
+        hipLaunchKernelGGL(k_chain_tables<true>, tgrid, dim3(kThreads), 0, s, b, 1);
+        hipLaunchKernelGGL(k_chain_compose, cgrid, dim3(kThreads), 0, s, b, 1);
+        hipLaunchKernelGGL(k_chain_stitch, dim3(b.maxseg, b.A), dim3(kScanThreads), lds, s, b, 1, (seq << 16) | (unsigned)(rep + 1));
+        if (hint) {
+            const unsigned long long want = (seq << 16) | (unsigned)(rep + 1);
+            unsigned long long w;
+            const bool seen = spin_until(b.h_progress, [&](unsigned long long v) { return (v >> 1) >= want; }, w);
+            if (!seen) { hint = false; t->chain_timeouts++; }
+            else if ((w >> 17) == seq && !(w & 1)) { clean = true; break; }
+        }
+    }
+    if (!clean) hipLaunchKernelGGL(k_chain_fallback, dim3(b.maxseg, b.A), dim3(64), 0, s, b);
+}
+
+// Sharded runs, round 6: the leaves' float sums from this rank's own pieces (rl_dist.inc, "piece mode"): three small all-gathers, no document leaves its rank.
+static int enqueue_leaf_chains_pieces(rl_trainer *t, const ChainSource &src)
+{
+    Ctx &c = t->ctx;
+    hipStream_t s = t->stream;
+    ChainBufs b = t->leaf_chain;
+    if (!(b.h_progress != nullptr && t->step_ahead > 0)) { b.progress = nullptr; b.h_progress = nullptr; }
+    const int R = t->n_ranks, me = t->dist->rank, A = b.A, MS = b.maxseg, nseg = std::max(c.L, 2), n = A * MS;
+    int rcd = t->dist->allgather(c.leaf_start, t->d_gls, (size_t)t->lsstride * sizeof(int32_t), s);       // the pieces' lengths on every rank
+    if (rcd) return rcd;
+    const unsigned tb = (unsigned)((b.cap_tiles + 3) / 4), nb = (unsigned)((n + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(k_chain_prefix, dim3(tb), dim3(kThreads), 0, s, b, src);
+    hipLaunchKernelGGL(k_chain_scan_tiles, dim3(b.A), dim3(kScanThreads), 0, s, b);
+    hipLaunchKernelGGL(k_piece_totals, dim3(nb), dim3(kThreads), 0, s, b, t->d_pc_loc);
+    rcd = t->dist->allgather(t->d_pc_loc, t->d_pc_all, (size_t)n * sizeof(double), s);
+    if (rcd) return rcd;
+    hipLaunchKernelGGL(k_piece_base, dim3(nb), dim3(kThreads), 0, s, (const double *)t->d_pc_all, n, me, t->d_pc_base, 0);
+    b.seg_base = t->d_pc_base; b.ptab = t->d_ptab;
+    hipLaunchKernelGGL(k_chain_bounds, dim3(tb, b.A), dim3(kThreads), 0, s, b);
+    const dim3 p1grid((unsigned)((b.cap_chunks * 16 + kThreads - 1) / kThreads), b.A);
+    hipLaunchKernelGGL(k_chain_pass1<false>, p1grid, dim3(kThreads), 0, s, b);
+    hipLaunchKernelGGL(k_piece_drifts, dim3(MS, b.A), dim3(64), 0, s, b, t->d_pc_loc);
+    rcd = t->dist->allgather(t->d_pc_loc, t->d_pc_all, (size_t)n * sizeof(double), s);
+    if (rcd) return rcd;
+    hipLaunchKernelGGL(k_piece_base, dim3(nb), dim3(kThreads), 0, s, (const double *)t->d_pc_all, n, me, t->d_pc_base, 1);
+    hipLaunchKernelGGL(k_chain_guess, dim3(b.A), dim3(kScanThreads), 0, s, b);
+    const dim3 tgrid((unsigned)((b.cap_chunks + kThreads / 64 - 1) / (kThreads / 64)), b.A);
+    const dim3 cgrid((unsigned)((b.cap_chunks / kChainBlock + kThreads / 64) / (kThreads / 64)), b.A);
+    const size_t lds = chain_stitch_lds(b);
+    const unsigned long long seq = ++t->chain_seq;
+    t->chain_calls[b.h_progress ? 0 : 1]++;
+    hipLaunchKernelGGL(k_chain_tables<false>, tgrid, dim3(kThreads), 0, s, b, 0);
+    hipLaunchKernelGGL(k_chain_compose, cgrid, dim3(kThreads), 0, s, b, 0);
+    hipLaunchKernelGGL(k_chain_stitch, dim3(b.maxseg, b.A), dim3(kScanThreads), lds, s, b, 0, seq << 16);
+    rcd = t->dist->allgather(t->d_ptab, t->d_gtab, (size_t)n * (kChainW + 1) * sizeof(uint32_t), s);
+    if (rcd) return rcd;
+    hipLaunchKernelGGL(k_chain_cross, dim3(1), dim3(kThreads), 0, s, (const uint32_t *)t->d_gtab, (const int32_t *)t->d_gls, t->lsstride, R, nseg, A, MS, me, t->xstate,
+                       (const uint32_t *)t->d_res_all, 0, t->piece_force, b.result, t->d_xmail, ++t->xmail_tag);
+    ChainBufs br = b; br.ptab = nullptr;            // (the repair passes stitch from ONE known state)
+    for (int round = 0;; round++) {
+        // every rank sees the same gathered tables, hence the same pending pieces: the rounds of this loop -- and their collectives -- are the same everywhere
+        const auto t0w = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (__atomic_load_n(&t->h_xmail[2], __ATOMIC_ACQUIRE) != t->xmail_tag) {
+            if ((++spins & 0xffff) == 0) {
+                const hipError_t q = hipStreamQuery(s);
+                if (q != hipSuccess && q != hipErrorNotReady) return fail(RL_ERR_HIP, std::string("device error in the leaves' float chains: ") + hipGetErrorString(q));
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0w).count() > t->dist_timeout_s)
+                    return fail(RL_ERR_COMM, "timed out waiting for the leaves' float chains (a rank of the job is missing from a collective?)");
+            }
+        }
+        const long long pend = t->h_xmail[0], mine = t->h_xmail[1];
+        if (pend == 0) break;
+        if (round > R * n + 8) return fail(RL_ERR_STATE, "the leaves' float chains did not close (internal error)");
+        t->piece_rounds++; t->piece_misses += pend;
+        hipLaunchKernelGGL(k_chain_arm, dim3(1), dim3(kThreads), 0, s, br, t->xstate, me, br.progress ? 1 : 0);
+        if (mine > 0) chain_repair_rounds(t, br, s);
+        hipLaunchKernelGGL(k_chain_resolved, dim3(1), dim3(kThreads), 0, s, br, t->xstate, me, t->d_res_loc);
+        rcd = t->dist->allgather(t->d_res_loc, t->d_res_all, (size_t)n * sizeof(uint32_t), s);
+        if (rcd) return rcd;
+        hipLaunchKernelGGL(k_chain_cross, dim3(1), dim3(kThreads), 0, s, (const uint32_t *)t->d_gtab, (const int32_t *)t->d_gls, t->lsstride, R, nseg, A, MS, me, t->xstate,
+                           (const uint32_t *)t->d_res_all, 1, t->piece_force, b.result, t->d_xmail, ++t->xmail_tag);
+    }
+    return RL_OK;
+}
+
 static void enqueue_metric_mean(rl_trainer *t, const double *ndcg_q, int Q, float *out, hipStream_t s = nullptr)
 {
     if (!s) s = t->stream;
@@ -1229,13 +1325,18 @@ static int enqueue_round(rl_trainer *t)
         // multi-GPU: gather lambda / weight in leaf order from every rank and evaluate the chains over the whole leaf
         // multi-GPU, the leaf-owner exchange (rl_dist.inc): lambda / weight of a leaf's documents go to the leaf's owner rank only
         ChainSource src{nullptr, nullptr, c.lw, c.idx[0], c.idx[1], t->d_seg_buf, stream_scores ? c.leaf_of : nullptr};
+        if (t->piece_chains) {      // round 6: every rank evaluates its own pieces of every leaf, only tables travel (rl_dist.inc)
+            int rcp = enqueue_leaf_chains_pieces(t, src);
+            if (rcp) return rcp;
+            hipLaunchKernelGGL(k_leaf_output, dim3((c.L + kThreads - 1) / kThreads), dim3(kThreads), 0, s, c, t->leaf_chain);
+        } else {
         const ChainBufs &lb = t->leaf_chain;
         const int R = t->n_ranks, me = t->dist->rank, nseg = std::max(c.L, 2), MS = t->gchain.maxseg;      // -leaf 1 still has two leaves (the root always splits)
         hipLaunchKernelGGL(k_chain_prefix, dim3((unsigned)((lb.cap_tiles + 3) / 4)), dim3(kThreads), 0, s, lb, src);      // local values in leaf order -> lb.xs
         int rcd = t->dist->allgather(c.leaf_start, t->d_gls, (size_t)t->lsstride * sizeof(int32_t), s);
         if (rcd) return rcd;
         std::vector<int64_t> scount(R), sdispl(R), rcount(R), rdispl(R);
-        const bool dev_plan = t->d_xmail != nullptr && nseg <= kPlanMaxSeg && R <= 64;
+        const bool dev_plan = t->d_xmail != nullptr && !getenv("RLHIP_DIST_HOST_PLAN") && nseg <= kPlanMaxSeg && R <= 64;       // (RLHIP_DIST_HOST_PLAN=1: the host plan behind a stream synchronisation, as until round 5)
         if (dev_plan) {
             // the plan on the device; the host only needs the byte counts of the transfers and reads them from a pinned mailbox below, after it has
             // enqueued the pack kernel (k_plan_exchange)
@@ -1305,6 +1406,7 @@ static int enqueue_round(rl_trainer *t)
                                MS, nseg, (const int32_t *)t->d_own, t->gchain.result);
         }
         hipLaunchKernelGGL(k_leaf_output, dim3((c.L + kThreads - 1) / kThreads), dim3(kThreads), 0, s, c, t->gchain);
+        }
     } else {   // K7: the two Java float running sums of every leaf, exactly, in parallel (rl_chain.inc)
         ChainSource src{nullptr, nullptr, c.lw, c.idx[0], c.idx[1], t->d_seg_buf, stream_scores ? c.leaf_of : nullptr};
         enqueue_chain(t, t->leaf_chain, src);
@@ -2342,18 +2444,32 @@ int rl_init(rl_trainer *t)
         if (rc) return rc;
         RL_HIP(t->pool.alloc(&t->d_seg_buf, (size_t)c.MAXN + 2));
         if (t->dist) {
-            rc = alloc_chain(t, t->gchain, c.MAXN + 1, 2, t->Nglobal, true);
-            if (rc) return rc;
             t->lsstride = c.MAXN + 2;
-            RL_HIP(t->pool.alloc(&t->d_gx, (size_t)2 * t->Nglobal + 2));              // at worst one rank owns every leaf
-            RL_HIP(t->pool.alloc(&t->d_send, (size_t)2 * N + 2));
-            RL_HIP(t->pool.alloc(&t->d_own, (size_t)c.MAXN + 1)); RL_HIP(t->pool.alloc(&t->d_xtab, (size_t)(c.MAXN + 1) * (t->n_ranks + 1)));
-            RL_HIP(t->pool.alloc(&t->d_gls, (size_t)t->n_ranks * t->lsstride));
-            // pinned mailbox of k_plan_exchange (RLHIP_DIST_HOST_PLAN=1: the host plan behind a stream synchronisation, as until round 5)
-            if (!getenv("RLHIP_DIST_HOST_PLAN") && !t->h_xmail && hipHostMalloc((void **)&t->h_xmail, (size_t)(4 * 64 + 1) * sizeof(long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+            // piece mode (rl_dist.inc): the leaves' float chains from every rank's own pieces; the leaf-owner exchange for what it does not cover
+            // (more than 256 leaves: the gathered tables grow with leaves x ranks; RL_FLAG_SERIAL_CHAIN) or on request (RLHIP_DIST_OWNER_CHAINS=1)
+            // pinned mailbox: the transfer sizes of k_plan_exchange / the pending pieces of k_chain_cross reach the host without a stream synchronisation
+            if (!t->h_xmail && hipHostMalloc((void **)&t->h_xmail, (size_t)(4 * 64 + 1) * sizeof(long long), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
                 memset(t->h_xmail, 0, (size_t)(4 * 64 + 1) * sizeof(long long));
                 if (hipHostGetDevicePointer((void **)&t->d_xmail, t->h_xmail, 0) != hipSuccess) { t->d_xmail = nullptr; (void)hipGetLastError(); }
             } else (void)hipGetLastError();
+            t->piece_force = getenv("RLHIP_PIECE_FORCE_MISS") ? atoi(getenv("RLHIP_PIECE_FORCE_MISS")) : 0;
+            t->piece_chains = t->d_xmail != nullptr && !getenv("RLHIP_DIST_OWNER_CHAINS") && c.MAXN + 1 <= 256 && t->n_ranks <= 64 && !(t->p.flags & RL_FLAG_SERIAL_CHAIN);
+            const bool owner_bufs = !t->piece_chains;
+            if (owner_bufs) { rc = alloc_chain(t, t->gchain, c.MAXN + 1, 2, t->Nglobal, true); if (rc) return rc; }
+            else { rc = alloc_chain(t, t->gchain, c.MAXN + 1, 2, 1024, true); if (rc) return rc; }       // (a stub: rl_get_array's statistics read leaf_chain in piece mode)
+            RL_HIP(t->pool.alloc(&t->d_gx, owner_bufs ? (size_t)2 * t->Nglobal + 2 : (size_t)2));              // at worst one rank owns every leaf
+            RL_HIP(t->pool.alloc(&t->d_send, owner_bufs ? (size_t)2 * N + 2 : (size_t)2));
+            if (t->piece_chains) {
+                const size_t n2 = (size_t)2 * (c.MAXN + 1), Rn = (size_t)t->n_ranks;
+                RL_HIP(t->pool.alloc(&t->d_pc_loc, n2)); RL_HIP(t->pool.alloc(&t->d_pc_all, Rn * n2)); RL_HIP(t->pool.alloc(&t->d_pc_base, n2));
+                RL_HIP(t->pool.alloc(&t->d_ptab, n2 * (kChainW + 1))); RL_HIP(t->pool.alloc(&t->d_gtab, Rn * n2 * (kChainW + 1)));
+                RL_HIP(t->pool.alloc(&t->d_res_loc, n2)); RL_HIP(t->pool.alloc(&t->d_res_all, Rn * n2));
+                RL_HIP(t->pool.alloc(&t->xstate.key, n2)); RL_HIP(t->pool.alloc(&t->xstate.rank, n2)); RL_HIP(t->pool.alloc(&t->xstate.pending, n2));
+                RL_HIP(hipMemset(t->xstate.key, 0, n2 * 4)); RL_HIP(hipMemset(t->xstate.rank, 0, n2 * 4)); RL_HIP(hipMemset(t->xstate.pending, 0, n2 * 4));
+                RL_HIP(hipMemset(t->d_res_all, 0, Rn * n2 * 4)); RL_HIP(hipMemset(t->d_ptab, 0, n2 * (kChainW + 1) * 4));
+            }
+            RL_HIP(t->pool.alloc(&t->d_own, (size_t)c.MAXN + 1)); RL_HIP(t->pool.alloc(&t->d_xtab, (size_t)(c.MAXN + 1) * (t->n_ranks + 1)));
+            RL_HIP(t->pool.alloc(&t->d_gls, (size_t)t->n_ranks * t->lsstride));
             RL_HIP(t->pool.alloc(&t->d_gres, (size_t)t->n_ranks * 2 * (c.MAXN + 1) + 8));
             RL_HIP(t->pool.alloc(&t->d_qsend, (size_t)t->Qmax)); RL_HIP(t->pool.alloc(&t->d_qgath, (size_t)t->n_ranks * t->Qmax));
             RL_HIP(t->pool.alloc(&t->d_qcat, (size_t)t->Qglobal)); RL_HIP(t->pool.alloc(&t->d_allQ, (size_t)t->n_ranks));
@@ -2685,6 +2801,12 @@ int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes)
     case RL_ARR_GROW_STATS: src = c.grow_stats; bytes = 16; break;
     case RL_ARR_GROW_DOCS: src = c.grow_docs; bytes = 32; break;
     case RL_ARR_BUBBLES: src = c.grow_docs + 4; bytes = 32; break;
+    case RL_ARR_PIECE_STATS: {
+        const int64_t v[2] = {t->piece_rounds, t->piece_misses};
+        if ((int64_t)sizeof(v) > cap_bytes) return fail(RL_ERR_INVALID, "output buffer too small");
+        memcpy(out, v, sizeof(v));
+        return RL_OK;
+    }
     case RL_ARR_SPARSE_INFO: {
         const int64_t v[8] = {c.sp_on ? c.sp_ngroups : 0, t->sp_entries, c.sp_on ? c.numFG - c.sp_ngroups : c.numFG, t->sp_cols,
                               c.crows ? t->cr_groups : 0, (int64_t)t->cr_entries, (int64_t)t->cr_overflow, c.cr_stride};
@@ -2715,7 +2837,7 @@ int rl_get_array(rl_trainer *t, int32_t which, void *out, int64_t cap_bytes)
         return RL_OK;
     }
     case RL_ARR_CHAIN_MISS: {
-        const ChainBufs &b = t->dist ? t->gchain : t->leaf_chain;
+        const ChainBufs &b = (t->dist && !t->piece_chains) ? t->gchain : t->leaf_chain;
         bytes = (size_t)2 * b.maxseg * 4;
         if ((int64_t)bytes > cap_bytes) return fail(RL_ERR_INVALID, "output buffer too small");
         RL_HIP(hipMemcpy(out, b.miss, bytes, hipMemcpyDeviceToHost));

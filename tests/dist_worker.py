@@ -75,7 +75,7 @@ def main():
     stats = g.array("CHAIN_STATS")
     if rank == 0:
         np.savez(out_path, scores=np.concatenate(parts), mets=np.array(mets), vmets=np.array(vmets), final=final, vfinal=(vfinal or 0.0), kept=g.num_trees(),
-                 dist_stats=g.dist_stats(), stats=stats, tie_stats=g.array("TIE_STATS"),
+                 dist_stats=g.dist_stats(), stats=stats, tie_stats=g.array("TIE_STATS"), piece_stats=g.array("PIECE_STATS"),
                  **{"t%d_%s" % (i, k): v for i, t in enumerate(trees) for k, v in t.items()})
     dist.barrier()
     dist.destroy_process_group()
