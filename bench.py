@@ -261,18 +261,19 @@ def scaling_model(docs_per_rank, world, steps_tree=10.8, ar_bytes=None):
     (profiles/r06f_sharded_one_rank_kernel_stats.txt / _timeline.txt: everything of the N > 1 path but the wire, 385 rounds/s against 429 of the plain path):
     kernels whose work is per document scale with the shard; a growth step (single-pass partition from local counts, child histograms, limb reduce,
     all-reduce, k_fin2<DIST>, k_select2) is ~112 us at 3.77 M documents per rank, of which ~70 us are the latency floor of its five dependent launches
-    whatever the shard size, and pays one all-reduce (ASSUMED 20 us + bytes at 40 GB/s effective ring bandwidth per rank over xGMI); the float chain of
-    the largest leaf has ONE owner rank (~60 % of all documents early in training)."""
+    whatever the shard size, and pays one all-reduce (ASSUMED 20 us + bytes at 40 GB/s effective ring bandwidth per rank over xGMI); the leaves' float
+    chains run on every rank's own pieces (rl_dist.inc piece mode, profiles/r06i_*: 0.30 ms at 3.77 M documents per rank + ~60 us of small launches and the
+    host's look at the walk's result + three small all-gathers, ASSUMED 15 us each)."""
     share = docs_per_rank / 3.77e6
     if ar_bytes is None:
         ar_bytes = 2.2 * 559e3          # ~2.2 slots of 559 KB per step on average at F = 136
     t_doc = (0.355 + 0.133 + 0.30 + 0.015) * share                 # lambdas, ranking + per-query metric, root pass + reduce + finish, score update
     t_step = steps_tree * (0.070 + 0.042 * share + (0.020 + ar_bytes / 40e9 * 1e3 if world > 1 else 0.0))
-    # leaf sums: gather in leaf order + exchange (pack, all-to-all, assemble) scale with the shard; the chains of a rank's own leaves with what it owns
-    t_leaf = 0.21 * max(share, 0.6 * share * world) + 0.12 * share + 0.08
+    # leaf sums (piece mode): gather in leaf order + the chain pipeline on the rank's own pieces scale with the shard; tables, totals and drifts are all-gathered
+    t_leaf = 0.30 * share + 0.06 + (0.045 if world > 1 else 0.0)
     return {"modelled_ms_per_round": t_doc + t_step + t_leaf, "modelled_rounds_per_s": 1000.0 / (t_doc + t_step + t_leaf), "world": world,
             "docs_per_rank": docs_per_rank, "growth_steps_per_tree": steps_tree, "allreduce_bytes_per_call": ar_bytes,
-            "note": "modelled = per-document kernels x shard share + growth steps x (70 us floor + 42 us x share + one all-reduce) + leaf sums (the largest leaf's chain has one owner)"}
+            "note": "modelled = per-document kernels x shard share + growth steps x (70 us floor + 42 us x share + one all-reduce) + leaf sums on every rank's own pieces (0.30 ms x share + 0.1)"}
 
 
 def main():
