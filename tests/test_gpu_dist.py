@@ -125,7 +125,7 @@ def test_k_shards_equal_one_shard(world, ranker, metric, k, cfg, tmp_path):
     # bench.py's counters in test_bench_entry_starts_its_own_ranks)
 
 
-@pytest.mark.parametrize("world,metric,k,opt", [(2, "NDCG", 10, "noa2a"), (3, "NDCG", 10, "piecemiss"), (3, "NDCG", 10, "ownerx"), (2, "NDCG", 10, "ownerx,noa2a"), (3, "NDCG", 10, "leafm1"), (2, "NDCG", 10, "qrel"), (3, "MAP", 0, "qrel"),
+@pytest.mark.parametrize("world,metric,k,opt", [(2, "NDCG", 10, "noa2a"), (3, "NDCG", 10, "piecemiss"), (2, "NDCG", 10, "countpass,ownerx"), (3, "NDCG", 10, "ownerx"), (2, "NDCG", 10, "ownerx,noa2a"), (3, "NDCG", 10, "leafm1"), (2, "NDCG", 10, "qrel"), (3, "MAP", 0, "qrel"),
                                                 (2, "NDCG", 10, "dupcols"), (3, "NDCG", 10, "dupcols,regrow"), (2, "NDCG", 10, "tcm1"), (3, "NDCG", 10, "tcm1")])
 def test_sharded_options(world, metric, k, opt, tmp_path):
     """ownerx: the leaf-owner exchange (RLHIP_DIST_OWNER_CHAINS=1; what runs beyond 256 leaves) instead of the distributed float chains: lambda / weight of a
@@ -142,6 +142,8 @@ def test_sharded_options(world, metric, k, opt, tmp_path):
         env["RLHIP_TIE_FORCE_REGROW"] = "1"
     if "ownerx" in opt:
         env["RLHIP_DIST_OWNER_CHAINS"] = "1"
+    if "countpass" in opt:       # round 5's sharded partition (count pass + two-pass scatter, chunks by the per-node rule) instead of the single pass from local cumulative counts
+        env["RLHIP_DIST_COUNT_PASS"] = "1"
     if "piecemiss" in opt:       # every piece of a leaf's chain behind the first is treated as a detected window miss: its rank re-evaluates it from the exact start
         env["RLHIP_PIECE_FORCE_MISS"] = "1"
     out = str(tmp_path / "o.npz")
