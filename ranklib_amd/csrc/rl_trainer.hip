@@ -1913,27 +1913,35 @@ int rl_init(rl_trainer *t)
                 // sample).  Every rank contributes its own sorted distinct values -- counts first, then the values padded to the largest count -- and merges
                 // what it receives; the overflow flags were all-reduced above, so the ranks take this branch for the same columns in the same order.
                 const int R = t->n_ranks;
-                int32_t *d_cnt = nullptr, *d_cnts = nullptr;
-                RL_HIP(hipMalloc((void **)&d_cnt, sizeof(int32_t))); RL_HIP(hipMalloc((void **)&d_cnts, (size_t)R * sizeof(int32_t)));
+                // (temporaries are released on every path -- DevTmp -- and nothing returns between the two collectives of a column for a LOCAL
+                // reason: a copy that fails is reported after the second all-gather, so the peers are not left waiting in it)
+                struct DevTmp { void *p = nullptr; ~DevTmp() { if (p) (void)hipFree(p); } hipError_t get(size_t bytes) { return hipMalloc(&p, bytes); } };
+                DevTmp t_cnt, t_cnts, t_v, t_all;
+                hipError_t herr = t_cnt.get(sizeof(int32_t));
+                if (herr == hipSuccess) herr = t_cnts.get((size_t)R * sizeof(int32_t));
+                if (herr != hipSuccess) return fail(RL_ERR_HIP, std::string("hipMalloc (threshold-table merge): ") + hipGetErrorString(herr));
                 const int32_t mycnt = (int32_t)vals.size();
-                RL_HIP(hipMemcpy(d_cnt, &mycnt, sizeof(int32_t), hipMemcpyHostToDevice));
-                int rcd = t->dist->allgather(d_cnt, d_cnts, sizeof(int32_t), s);
+                herr = hipMemcpy(t_cnt.p, &mycnt, sizeof(int32_t), hipMemcpyHostToDevice);
+                int rcd = t->dist->allgather(t_cnt.p, t_cnts.p, sizeof(int32_t), s);
+                if (rcd) return rcd;
                 std::vector<int32_t> cnts((size_t)R);
-                if (!rcd) { RL_HIP(hipStreamSynchronize(s)); RL_HIP(hipMemcpy(cnts.data(), d_cnts, (size_t)R * sizeof(int32_t), hipMemcpyDeviceToHost)); }
-                (void)hipFree(d_cnt); (void)hipFree(d_cnts);
+                if (herr == hipSuccess) herr = hipStreamSynchronize(s);
+                if (herr == hipSuccess) herr = hipMemcpy(cnts.data(), t_cnts.p, (size_t)R * sizeof(int32_t), hipMemcpyDeviceToHost);
+                if (herr != hipSuccess) return fail(RL_ERR_HIP, std::string("threshold-table merge (counts): ") + hipGetErrorString(herr));
+                const size_t mx = std::max<size_t>((size_t)*std::max_element(cnts.begin(), cnts.end()), 1);
+                herr = t_v.get(mx * sizeof(float));
+                if (herr == hipSuccess) herr = t_all.get(mx * R * sizeof(float));
+                if (herr != hipSuccess) return fail(RL_ERR_HIP, std::string("hipMalloc (threshold-table merge): ") + hipGetErrorString(herr));
+                herr = hipMemset(t_v.p, 0, mx * sizeof(float));
+                if (herr == hipSuccess && !vals.empty()) herr = hipMemcpy(t_v.p, vals.data(), vals.size() * sizeof(float), hipMemcpyHostToDevice);
+                rcd = t->dist->allgather(t_v.p, t_all.p, mx * sizeof(float), s);
                 if (rcd) return rcd;
-                const size_t mx = (size_t)*std::max_element(cnts.begin(), cnts.end());
-                float *d_v = nullptr, *d_all = nullptr;
-                RL_HIP(hipMalloc((void **)&d_v, std::max<size_t>(mx, 1) * sizeof(float))); RL_HIP(hipMalloc((void **)&d_all, std::max<size_t>(mx, 1) * R * sizeof(float)));
-                RL_HIP(hipMemset(d_v, 0, std::max<size_t>(mx, 1) * sizeof(float)));
-                RL_HIP(hipMemcpy(d_v, vals.data(), vals.size() * sizeof(float), hipMemcpyHostToDevice));
-                rcd = t->dist->allgather(d_v, d_all, std::max<size_t>(mx, 1) * sizeof(float), s);
-                std::vector<float> all(std::max<size_t>(mx, 1) * R);
-                if (!rcd) { RL_HIP(hipStreamSynchronize(s)); RL_HIP(hipMemcpy(all.data(), d_all, all.size() * sizeof(float), hipMemcpyDeviceToHost)); }
-                (void)hipFree(d_v); (void)hipFree(d_all);
-                if (rcd) return rcd;
+                std::vector<float> all(mx * R);
+                if (herr == hipSuccess) herr = hipStreamSynchronize(s);
+                if (herr == hipSuccess) herr = hipMemcpy(all.data(), t_all.p, all.size() * sizeof(float), hipMemcpyDeviceToHost);
+                if (herr != hipSuccess) return fail(RL_ERR_HIP, std::string("threshold-table merge (values): ") + hipGetErrorString(herr));
                 vals.clear();
-                for (int r = 0; r < R; r++) vals.insert(vals.end(), all.begin() + (size_t)r * std::max<size_t>(mx, 1), all.begin() + (size_t)r * std::max<size_t>(mx, 1) + cnts[r]);
+                for (int r = 0; r < R; r++) vals.insert(vals.end(), all.begin() + (size_t)r * mx, all.begin() + (size_t)r * mx + cnts[r]);
                 std::sort(vals.begin(), vals.end());
                 vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
                 if (!vals.empty()) { fmin = vals.front(); fmax = vals.back(); }
