@@ -95,6 +95,7 @@ def bench_infer(args):
     # there is nothing to exchange in Ensemble.eval).  gloo only carries the barrier and the max of the elapsed times.
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return respawn(args.gpus)
+    claim_stdout()
     world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
@@ -222,7 +223,30 @@ def bench_infer(args):
                                "sample": "the first %d rows of the same batch, same %d trees, C restatement of Ensemble.eval with the rows split "
                                          "over %d threads; scores identical to the GPU's: %s" % (ns, nt, threads, same)}
         out["speedup_vs_cpu_baseline"] = docs_per_s / (ns / t_cpu)
-    print(json.dumps(out))
+    emit(json.dumps(out))
+
+
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too -- gloo announces its connections, RCCL prints a version banner through the C
+    library's buffered stdout when a communicator is created (it would be flushed BEHIND the JSON line at exit) -- so for the life of the process file
+    descriptor 1 points at stderr and only emit() writes to the real stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        print(line)
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, (line + "\n").encode())
 
 
 def init_control_plane():
@@ -324,6 +348,7 @@ def main():
         local_rank = 0
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return respawn(args.gpus)
+    claim_stdout()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: run `python bench.py --gpus N` (it starts its own ranks) or launch N ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
@@ -722,7 +747,7 @@ def main():
                       "(init %.1f s not counted)" % (args.cpu_rounds, t_cpu_init),
         }
         out["speedup_vs_cpu_baseline"] = rounds_per_s / (args.cpu_rounds / t_cpu)
-    print(json.dumps(out))
+    emit(json.dumps(out))
 
 
 if __name__ == "__main__":

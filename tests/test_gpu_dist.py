@@ -185,6 +185,22 @@ def test_bench_entry_starts_its_own_ranks():
         assert o["config"]["docs_total"] == (20000 if extra else 10000)
 
 
+def test_bench_stdout_is_one_json_line_with_an_rccl_communicator_in_the_process():
+    """RCCL prints a version banner through the C library's buffered stdout when a communicator is created -- it used to land BEHIND the JSON line when
+    the process ended (the default run creates a one-rank communicator for config.sharded_path_one_rank).  bench.py points file descriptor 1 at stderr
+    for its whole life and writes the line to the real stdout itself: stdout holds the one line, nothing else."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--shape", "c0", "--plain", "--sharded-one-rank"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), "stdout must hold the one JSON line and nothing else: " + r.stdout[-2000:]
+    o = json.loads(lines[0])
+    assert o["n_gpus"] == 1 and o["value"] > 0
+
+
 def _run_workers(world, cfg, out, extra, port):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
