@@ -178,6 +178,29 @@ def bench_infer(args):
         elapsed = float(tt.item())
     ms = e0.elapsed_time(e1) / args.steps
     docs_per_s = n * world * args.steps / elapsed
+    # --infer-ab VAR=v1,v2,..: the same rows with an environment knob of the kernel set to each value (one warm-up + `--steps` timed passes each), and
+    # whether every value left the same score bits (RLHIP_EVAL_COMPACT=1,0: rank-coded against float cells)
+    variants = {}
+    if args.infer_ab:
+        var, vals = args.infer_ab.split("=", 1)
+        ref_bits = None
+        for v in vals.split(","):
+            os.environ[var] = v
+            for kv in v.split("+")[1:]:          # "1+OTHER=3": further knobs for this value
+                os.environ[kv.split(":")[0]] = kv.split(":")[1]
+            m.predict_device(dX.data_ptr(), n, stride, dO.data_ptr())
+            torch.cuda.synchronize()
+            tv = time.perf_counter()
+            for _ in range(args.steps):
+                m.predict_device(dX.data_ptr(), n, stride, dO.data_ptr())
+            torch.cuda.synchronize()
+            tv = time.perf_counter() - tv
+            bi = dO.view(torch.int32).to(torch.int64)
+            bits = (int(bi.sum().item()), int((bi * (torch.arange(n, device="cuda") % 8191 + 1)).sum().item()))
+            if ref_bits is None:
+                ref_bits = bits
+            variants["%s=%s" % (var, v)] = {"docs_per_s": n * args.steps / tv, "same_bits_as_first": bits == ref_bits}
+        os.environ.pop(var, None)
     if rank != 0:
         return
     out = {
@@ -188,7 +211,7 @@ def bench_infer(args):
         "config": {"workload": "c4 (BASELINE.json configs[4]) inference: %d documents x %d features per GPU resident in HBM, %d GPU(s) as independent replicas, "
                                "%d trees (%d trained rounds tiled), 31 leaves" % (n, F, world, nt, args.infer_train_rounds),
                    "mean_node_visits_per_tree": visits, "node_visits_per_s": docs_per_s * nt * visits,
-                   "model_parse_seconds": round(t_load, 2)},
+                   "model_parse_seconds": round(t_load, 2), "same_rows_ab": variants},
         "roofline": {
             # the walk is bound by instruction issue, not by bytes: a chain step is 5 vector-ALU + 2 LDS wave-instructions for 64 lanes (HISTORY.md 4.8).
             # peak = what the four SIMDs of a CU issue if they did nothing else: 4 SIMDs x 64 lanes / (5 VALU x 4 cycles) lane-steps per CU and clock.
@@ -328,6 +351,7 @@ def main():
     ap.add_argument("--trees", type=int, default=10000, help="infer: trees in the scored model")
     ap.add_argument("--docs", type=int, default=100000000, help="infer: rows per GPU and step (configs[4]: 100 M = 54.8 GB of rows in HBM)")
     ap.add_argument("--infer-train-rounds", type=int, default=100)
+    ap.add_argument("--infer-ab", default="", help="infer: time the same rows with an environment knob at several values, e.g. RLHIP_EVAL_COMPACT=1,0")
     args = ap.parse_args()
     if args.plain:
         args.cpu_rounds, args.sustain, args.node_rounds, args.no_pmc, args.no_timing, args.c1_trees, args.ns_rounds, args.c2_trees, args.shard1_rounds = 0, 0, 0, True, True, 0, 0, 0, 0

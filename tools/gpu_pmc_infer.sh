@@ -20,7 +20,7 @@ dbs = glob.glob('$d/**/*.db', recursive=True)
 if dbs:
     con = sqlite3.connect(dbs[0])
     for name, ctr, n, avg in con.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name order by kernel_name"):
-        if "k_model_eval_tiled" in name:
+        if "k_model_eval" in name:
             print("%-40s %-22s launches %3d  avg per launch %18.1f" % (name[:40], ctr, n, avg))
 else:
     print("(no counters for: $ctr)")
