@@ -133,14 +133,27 @@ def bench_infer(args):
             if t["feature"][i] != -1:
                 d[int(t["left"][i])] = d[int(t["right"][i])] = d[i] + 1
         return int(d.max())
-    # lockstep walk length per tree as the kernel deals the trees of a 32-tree tile to its four walker wavefronts (by descending depth, eight each)
+    # chain steps per tree as the kernel walks them: the trees of a 32-tree tile go to its four walker wavefronts by descending depth, eight each; a walker runs
+    # all eight chains for as many steps as its 7th tree has levels, then six to its 5th tree's depth, four to its 3rd's, two to its deepest's (round 6;
+    # until then: all eight to the deepest -- `lockstep_steps_per_tree`)
     dep = np.array([max(depth_of(trees[i % len(trees)]), 1) for i in range(args.trees)])
-    steps_sum = 0
+    steps_sum = lock_sum = 0
     for a in range(0, len(dep), 32):
         ds_ = np.sort(dep[a:a + 32])[::-1]
         for q in range(0, len(ds_), 8):
-            steps_sum += int(ds_[q]) * len(ds_[q:q + 8])
+            g = [int(v) for v in ds_[q:q + 8]]
+            lock_sum += g[0] * len(g)
+            prev, done = 0, 0
+            for n_ch, nxt in ((8, 6), (6, 4), (4, 2), (2, 0)):        # chains walking, index of the tree whose depth ends the phase
+                end = g[nxt] if nxt < len(g) else 0
+                if nxt == 0:
+                    end = g[0]
+                if end > prev:
+                    done += min(n_ch, len(g)) * (end - prev)
+                    prev = end
+            steps_sum += done
     walk_steps = steps_sum / float(len(dep))
+    lock_steps = lock_sum / float(len(dep))
     n = args.docs
     stride = F + 1
     gen = torch.Generator(device="cuda").manual_seed(20240601 + rank)
@@ -219,12 +232,12 @@ def bench_infer(args):
             "achieved": docs_per_s / world * nt * walk_steps / (256 * 2.4e9), "peak": 4 * 64 / (5 * 4.0), "unit": "lane-steps per CU and clock",
             "frac": docs_per_s / world * nt * walk_steps / (256 * 2.4e9) / (4 * 64 / (5 * 4.0)),
             "lds_pipe_peak": 64 / ((256 + 512) / 128.0),
-            "walk_steps_per_tree": walk_steps, "mean_path_nodes_per_tree": visits, "lane_use": visits / walk_steps,
+            "walk_steps_per_tree": walk_steps, "lockstep_steps_per_tree": lock_steps, "mean_path_nodes_per_tree": visits, "lane_use": visits / walk_steps,
             "useful_node_visits_per_cu_clock": docs_per_s / world * nt * visits / (256 * 2.4e9),
             "hbm": {"achieved": n * stride * 4.0 / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": n * stride * 4.0 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "traffic": None,
             "note": "every row is read from HBM once and walked %d x %.1f steps in LDS: HBM is at a fraction of a percent.  A lane-step = one lane advancing one node "
-                    "(leaves repeat themselves until the deepest tree of the wavefront's eight is done); lds_pipe_peak = 64 lanes / (768 B per wave-step / 128 B per clock); "
+                    "(a leaf repeats itself until its chain's phase ends: eight chains to the walker's 7th-deepest tree, six to the 5th, four to the 3rd, two to the deepest); lds_pipe_peak = 64 lanes / (768 B per wave-step / 128 B per clock); "
                     "counters: profiles/r04_infer_*" % (nt, walk_steps)},
     }
     if args.cpu_rounds > 0:

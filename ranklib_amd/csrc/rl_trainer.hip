@@ -3125,10 +3125,24 @@ __global__ __launch_bounds__(kThreads) void k_model_eval(const EnsTree e, const 
 #endif
 constexpr int kEvalDocs = 64, kEvalParts = RL_EVAL_PARTS, kEvalPer = RL_EVAL_PER, kEvalTreeTile = kEvalParts * kEvalPer;
 constexpr int kEvalThreads = kEvalDocs * (kEvalParts + 1), kEvalPrefetch = 8;     // 8-byte words each thread prefetches per tile
+// Phases of a walker's walk (round 6; see the loop): chains still walking after the first phase, the second, .. and in the last one.  Same box,
+// alternating libraries, 30 M rows x 10 000 trees (profiles/r06w_ab_infer_phased_walk.txt): one loop of eight chains 26.8 M docs/s | 8 -> 4: 27.9 |
+// 8 -> 4 -> 2: 27.5 | 8 -> 6 -> 4 -> 2: 28.3 - 28.5 | a staircase 8 -> 7 -> .. -> 1: 23.3.
+#ifndef RL_EVAL_PHASES
+#define RL_EVAL_PHASES 3
+#endif
+#if RL_EVAL_PHASES == 1
+constexpr int kEvalPhases = 1, kEvalPh1 = 4, kEvalPh2 = 2, kEvalPhLast = 4;
+#elif RL_EVAL_PHASES == 2
+constexpr int kEvalPhases = 2, kEvalPh1 = 4, kEvalPh2 = 2, kEvalPhLast = 2;
+#else
+constexpr int kEvalPhases = 3, kEvalPh1 = 6, kEvalPh2 = 4, kEvalPhLast = 2;
+#endif
+constexpr int kEvalMetaDepths = kEvalParts * (1 + kEvalPhases);      // per tile: every walker's steps, then the steps at which its phases end
 
 static inline size_t eval_tiled_lds(int cols, int maxn)
 {
-    return (size_t)cols * kEvalDocs * 4 + (size_t)kEvalTreeTile * maxn * 8 + (size_t)2 * kEvalTreeTile * kEvalDocs * 4 + 2 * kEvalTreeTile * 4 + 2 * (kEvalTreeTile + 8);
+    return (size_t)cols * kEvalDocs * 4 + (size_t)kEvalTreeTile * maxn * 8 + (size_t)2 * kEvalTreeTile * kEvalDocs * 4 + 2 * kEvalTreeTile * 4 + 2 * (kEvalTreeTile + kEvalMetaDepths);
 }
 
 // cols = max(row_stride, largest column any node reads + 1)
@@ -3137,9 +3151,11 @@ static inline size_t eval_tiled_lds(int cols, int maxn)
 // -infinity there -- so `x <= value` is always true and its left-child offset is its own.  A chain step is then the same eight instructions for
 // every node (and, add, ds_read_b32, shift, compare, select, add3, ds_read_b64) with no leaf test and no branch, so the compiler issues the eight
 // chains' feature loads back to back and their node loads back to back: the wavefront waits for LDS twice per step of EIGHT chains instead of
-// twice per chain (the branchy version spent half of its time in those waits: 2.5 walker wavefronts per SIMD cannot hide them).  A walker runs
-// as many steps as its deepest tree has levels; the trees of a tile are dealt to the walkers by depth (perm / gdepth, built with the packing), so
-// shallow trees do not idle behind a deep one.  The accumulator adds the outputs in the ensemble's own order whatever walker produced them.
+// twice per chain (the branchy version spent half of its time in those waits: 2.5 walker wavefronts per SIMD cannot hide them).  The trees of a
+// tile are dealt to the walkers by depth (perm / gdepth, built with the packing), deepest first inside a walker; a walker's deepest tree sets its
+// number of steps, and since round 6 its chains drop out in phases as their trees end -- eight chains to the 7th tree's depth, six to the 5th's, four to the
+// 3rd's, two to the deepest's (see kEvalPhases) -- instead of all eight idling on their leaves to the last step: 26.8 -> 28.4 M docs/s.  The accumulator
+// adds the outputs in the ensemble's own order whatever walker produced them.
 __global__ __launch_bounds__(kEvalThreads) void k_model_eval_tiled(const unsigned long long *nodes, const float *w, int MAXN, int nt,
                                                                    const float *X, int64_t n, int stride, int cols, float *out,
                                                                    const unsigned char *perm, const unsigned char *gdepth)
@@ -3149,7 +3165,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_model_eval_tiled(const unsigne
     unsigned long long *sT = (unsigned long long *)(sX + (size_t)cols * kEvalDocs);   // [kEvalTreeTile][MAXN]
     float *sO = (float *)(sT + (size_t)kEvalTreeTile * MAXN);                  // [2][kEvalTreeTile][kEvalDocs] leaf outputs (double buffer)
     float *sW = sO + 2 * kEvalTreeTile * kEvalDocs;                            // [2][kEvalTreeTile] tree weights
-    unsigned char *sP = (unsigned char *)(sW + 2 * kEvalTreeTile);             // [2][kEvalTreeTile + 8] the tile's walker assignment and walk lengths
+    unsigned char *sP = (unsigned char *)(sW + 2 * kEvalTreeTile);             // [2][kEvalTreeTile + kEvalMetaDepths] the tile's walker assignment and walk lengths
     const int tid = threadIdx.x, doc = tid & (kEvalDocs - 1), part = tid / kEvalDocs;
     const bool walker = part < kEvalParts;
     const int tile_words = kEvalTreeTile * MAXN;                               // <= kEvalThreads * kEvalPrefetch (checked by the host)
@@ -3175,8 +3191,8 @@ __global__ __launch_bounds__(kEvalThreads) void k_model_eval_tiled(const unsigne
 #pragma unroll
             for (int u = 0; u < kEvalPrefetch; u++) { const int e = tid + u * kEvalThreads; if (e < tile_words) sT[e] = pre[u]; }
             if (tid < tt) sW[cb * kEvalTreeTile + tid] = w[t0 + tid];
-            if (tid < kEvalTreeTile) sP[cb * (kEvalTreeTile + 8) + tid] = perm[(size_t)k * kEvalTreeTile + tid];
-            else if (tid < kEvalTreeTile + kEvalParts) sP[cb * (kEvalTreeTile + 8) + tid] = gdepth[(size_t)k * kEvalParts + (tid - kEvalTreeTile)];
+            if (tid < kEvalTreeTile) sP[cb * (kEvalTreeTile + kEvalMetaDepths) + tid] = perm[(size_t)k * kEvalTreeTile + tid];
+            else if (tid < kEvalTreeTile + kEvalMetaDepths) sP[cb * (kEvalTreeTile + kEvalMetaDepths) + tid] = gdepth[(size_t)k * kEvalMetaDepths + (tid - kEvalTreeTile)];
             __syncthreads();
             {   // next tile -> registers (in flight during the walk)
                 const size_t nb = (size_t)(t0 + kEvalTreeTile) * MAXN;
@@ -3185,7 +3201,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_model_eval_tiled(const unsigne
                 for (int u = 0; u < kEvalPrefetch; u++) { const int e = tid + u * kEvalThreads; pre[u] = (e < tile_words && e < left) ? nodes[nb + e] : 0ull; }
             }
             if (walker) {
-                const unsigned char *pp = sP + cb * (kEvalTreeTile + 8);
+                const unsigned char *pp = sP + cb * (kEvalTreeTile + kEvalMetaDepths);
                 const int depth = __builtin_amdgcn_readfirstlane((int)pp[kEvalTreeTile + part]);      // wave-uniform: a scalar loop bound
                 if (depth > 0) {
                     float *so = sO + (size_t)cb * kEvalTreeTile * kEvalDocs + doc;
@@ -3198,16 +3214,32 @@ __global__ __launch_bounds__(kEvalThreads) void k_model_eval_tiled(const unsigne
                         tb[u] = (const unsigned char *)(sT + (size_t)(li[u] < tt ? li[u] : 0) * MAXN);
                         v[u] = *(const unsigned long long *)tb[u];
                     }
-                    for (int step = 0; step < depth; step++) {
-                        float x[kEvalPer];
-#pragma unroll
-                        for (int u = 0; u < kEvalPer; u++) x[u] = *(const float *)(sXb + ((unsigned)(v[u] >> 32) & 0xffffu));
-#pragma unroll
-                        for (int u = 0; u < kEvalPer; u++) {                   // Split.eval: value <= threshold goes left (Split.java:118); a leaf stays where it is
-                            const unsigned off = (unsigned)(v[u] >> 48) + ((x[u] <= __uint_as_float((unsigned)v[u])) ? 0u : 8u);
-                            v[u] = *(const unsigned long long *)(tb[u] + off);
-                        }
+                    // The walker's trees come deepest first.  All eight chains walk for as many steps as the walker's (kEvalPh1 + 1)-th tree has levels, then the
+                    // kEvalPh1 deepest for as many as the (kEvalPh2 + 1)-th has, ... : a chain that has reached its leaf in every lane stops costing instructions
+                    // (in ONE loop to the deepest tree's depth the shallow chains idled on their leaves, at the cost of their instructions).
+                    int step = 0;
+#define RL_EVAL_PHASE(NCH, UNTIL)                                                                                                          \
+                    for (; step < (UNTIL); step++) {                                                                                       \
+                        float x[NCH];                                                                                                      \
+                        _Pragma("unroll") for (int u = 0; u < NCH; u++) x[u] = *(const float *)(sXb + ((unsigned)(v[u] >> 32) & 0xffffu)); \
+                        _Pragma("unroll") for (int u = 0; u < NCH; u++) {       /* Split.eval: value <= threshold goes left (Split.java:118); a leaf stays where it is */ \
+                            const unsigned off = (unsigned)(v[u] >> 48) + ((x[u] <= __uint_as_float((unsigned)v[u])) ? 0u : 8u);           \
+                            v[u] = *(const unsigned long long *)(tb[u] + off);                                                             \
+                        }                                                                                                                  \
                     }
+                    const unsigned char *pd = pp + kEvalTreeTile + kEvalParts + part * kEvalPhases;
+                    const int end0 = __builtin_amdgcn_readfirstlane((int)pd[0]);           // (scalar loop bounds, read once)
+                    [[maybe_unused]] const int end1 = __builtin_amdgcn_readfirstlane((int)pd[kEvalPhases >= 2 ? 1 : 0]);
+                    [[maybe_unused]] const int end2 = __builtin_amdgcn_readfirstlane((int)pd[kEvalPhases >= 3 ? 2 : 0]);
+                    RL_EVAL_PHASE(kEvalPer, end0)
+#if RL_EVAL_PHASES >= 2
+                    RL_EVAL_PHASE(kEvalPh1, end1)
+#endif
+#if RL_EVAL_PHASES >= 3
+                    RL_EVAL_PHASE(kEvalPh2, end2)
+#endif
+                    RL_EVAL_PHASE(kEvalPhLast, depth)
+#undef RL_EVAL_PHASE
                     if (doc < nd) {
 #pragma unroll
                         for (int u = 0; u < kEvalPer; u++) if (li[u] < tt) so[li[u] * kEvalDocs] = __uint_as_float((unsigned)v[u]);
@@ -3307,7 +3339,7 @@ int rl_model_from_text(const char *text, int32_t device, rl_model **out)
             if (ok) {
                 // the trees of a tile go to the walker wavefronts by descending depth (stable), eight each
                 const size_t ntl = (nt + kEvalTreeTile - 1) / kEvalTreeTile;
-                std::vector<unsigned char> pm(ntl * kEvalTreeTile, 255), gd(ntl * kEvalParts, 0);
+                std::vector<unsigned char> pm(ntl * kEvalTreeTile, 255), gd(ntl * kEvalMetaDepths, 0);       // gd: per tile the walkers' steps, then per walker the steps at which its phases end
                 std::vector<int> idx;
                 for (size_t tl = 0; tl < ntl; tl++) {
                     const size_t t0 = tl * kEvalTreeTile, tt = std::min<size_t>(kEvalTreeTile, nt - t0);
@@ -3316,9 +3348,19 @@ int rl_model_from_text(const char *text, int32_t device, rl_model **out)
                     std::stable_sort(idx.begin(), idx.end(), [&](int a2, int b2) { return tdepth[t0 + a2] > tdepth[t0 + b2]; });
                     for (size_t q = 0; q < tt; q++) {
                         pm[tl * kEvalTreeTile + q] = (unsigned char)idx[q];
-                        unsigned char &g = gd[tl * kEvalParts + q / kEvalPer];
+                        unsigned char &g = gd[tl * kEvalMetaDepths + q / kEvalPer];
                         g = std::max<unsigned char>(g, (unsigned char)std::max(tdepth[t0 + idx[q]], 1));      // (a single-leaf tree still stores its output: one step)
                     }
+                    // a phase of n chains ends when the walker's (n' + 1)-th tree (n' = the next phase's chains) is done: that tree's depth.  A walker with fewer
+                    // trees: 0 (the phase is skipped).  RLHIP_EVAL_PHASED=0: every phase runs to the walker's full depth (one loop, rounds 4 - 5).
+                    static const bool phased = !(getenv("RLHIP_EVAL_PHASED") && atoi(getenv("RLHIP_EVAL_PHASED")) == 0);
+                    const int next_ch[3] = {kEvalPhases >= 2 ? kEvalPh1 : kEvalPhLast, kEvalPhases >= 3 ? kEvalPh2 : kEvalPhLast, kEvalPhLast};
+                    for (int p = 0; p < kEvalParts; p++)
+                        for (int ph = 0; ph < kEvalPhases; ph++) {
+                            const size_t q = (size_t)p * kEvalPer + next_ch[ph];
+                            unsigned char &e = gd[tl * kEvalMetaDepths + kEvalParts + p * kEvalPhases + ph];
+                            e = !phased ? gd[tl * kEvalMetaDepths + p] : (q < tt ? (unsigned char)std::max(tdepth[t0 + idx[q]], 1) : 0);
+                        }
                 }
                 RL_HIP(m->pool.alloc(&m->d_perm, pm.size())); RL_HIP(m->pool.alloc(&m->d_gdepth, gd.size()));
                 RL_HIP(hipMemcpy(m->d_perm, pm.data(), pm.size(), hipMemcpyHostToDevice));
