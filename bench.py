@@ -133,15 +133,17 @@ def bench_infer(args):
             if t["feature"][i] != -1:
                 d[int(t["left"][i])] = d[int(t["right"][i])] = d[i] + 1
         return int(d.max())
-    # chain steps per tree as the kernel walks them: the trees of a 32-tree tile go to its four walker wavefronts by descending depth, eight each; a walker runs
+    # chain steps per tree as the kernel walks them: the trees of a 32-tree tile, sorted by depth, are dealt round its four walker wavefronts; a walker runs
     # all eight chains for as many steps as its 7th tree has levels, then six to its 5th tree's depth, four to its 3rd's, two to its deepest's (round 6;
     # until then: all eight to the deepest -- `lockstep_steps_per_tree`)
     dep = np.array([max(depth_of(trees[i % len(trees)]), 1) for i in range(args.trees)])
     steps_sum = lock_sum = 0
     for a in range(0, len(dep), 32):
         ds_ = np.sort(dep[a:a + 32])[::-1]
-        for q in range(0, len(ds_), 8):
-            g = [int(v) for v in ds_[q:q + 8]]
+        # a full tile's sorted trees are dealt round the four walkers (walker p: ranks p, p + 4, ..), a partial last tile eight consecutive ranks each
+        groups = [ds_[p::4] for p in range(4)] if len(ds_) == 32 else [ds_[q:q + 8] for q in range(0, len(ds_), 8)]
+        for grp in groups:
+            g = [int(v) for v in grp]
             lock_sum += g[0] * len(g)
             prev, done = 0, 0
             for n_ch, nxt in ((8, 6), (6, 4), (4, 2), (2, 0)):        # chains walking, index of the tree whose depth ends the phase

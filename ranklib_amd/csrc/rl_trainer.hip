@@ -3152,7 +3152,7 @@ static inline size_t eval_tiled_lds(int cols, int maxn)
 // every node (and, add, ds_read_b32, shift, compare, select, add3, ds_read_b64) with no leaf test and no branch, so the compiler issues the eight
 // chains' feature loads back to back and their node loads back to back: the wavefront waits for LDS twice per step of EIGHT chains instead of
 // twice per chain (the branchy version spent half of its time in those waits: 2.5 walker wavefronts per SIMD cannot hide them).  The trees of a
-// tile are dealt to the walkers by depth (perm / gdepth, built with the packing), deepest first inside a walker; a walker's deepest tree sets its
+// tile, sorted by depth, are dealt round the walkers (perm / gdepth, built with the packing), deepest first inside a walker; a walker's deepest tree sets its
 // number of steps, and since round 6 its chains drop out in phases as their trees end -- eight chains to the 7th tree's depth, six to the 5th's, four to the
 // 3rd's, two to the deepest's (see kEvalPhases) -- instead of all eight idling on their leaves to the last step: 26.8 -> 28.4 M docs/s.  The accumulator
 // adds the outputs in the ensemble's own order whatever walker produced them.
@@ -3346,6 +3346,16 @@ int rl_model_from_text(const char *text, int32_t device, rl_model **out)
                     idx.resize(tt);
                     for (size_t q = 0; q < tt; q++) idx[q] = (int)q;
                     std::stable_sort(idx.begin(), idx.end(), [&](int a2, int b2) { return tdepth[t0 + a2] > tdepth[t0 + b2]; });
+                    // The sorted trees are dealt ROUND the walkers (walker p: ranks p, p + 4, p + 8, ..; deepest first inside a walker as the phases need it): every
+                    // walker spans the tile's whole range of depths, so its chains drop out early and the four walkers reach the tile's barrier together.
+                    // With eight consecutive ranks each (rounds 4 - 5, RLHIP_EVAL_DEAL=0) walker 0 held the eight deepest trees -- little to drop, and the others
+                    // waited for it: 28.2 against 28.8 M docs/s (profiles/r06w_ab_infer_phased_walk.txt).
+                    static const bool deal_rr = !(getenv("RLHIP_EVAL_DEAL") && atoi(getenv("RLHIP_EVAL_DEAL")) == 0);
+                    if (deal_rr && tt == (size_t)kEvalTreeTile) {
+                        std::vector<int> rr(tt);
+                        for (size_t q = 0; q < tt; q++) rr[(q % kEvalParts) * kEvalPer + q / kEvalParts] = idx[q];
+                        idx = rr;
+                    }
                     for (size_t q = 0; q < tt; q++) {
                         pm[tl * kEvalTreeTile + q] = (unsigned char)idx[q];
                         unsigned char &g = gd[tl * kEvalMetaDepths + q / kEvalPer];
